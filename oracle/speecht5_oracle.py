@@ -1,0 +1,225 @@
+"""CPU oracle for the SpeechT5 speech-encoder embedding path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and
+the ``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``loco-asr_amd``) never does, and fails loudly when its HIP library is missing.
+
+What it restates
+----------------
+The reference (`/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:108-109`)
+calls ``model.speecht5.encoder(**audios).last_hidden_state``; the arithmetic lives in the
+third-party dependency ``transformers`` (pinned ``==4.30.2`` in
+`/root/reference/speech_text/requirements.txt:151`; 5.15.0 is what this image carries; same
+maths for this path).  ``HF:`` line numbers below are for
+``transformers/models/speecht5/modeling_speecht5.py`` 5.15.0.
+
+The functions here are fresh code in plain torch CPU ops.  They differ from the HF module in
+structure where HF cannot scale: the relative-position bias is evaluated in its compact form
+``bias[i,j] = (q_i . pe_k^T)[clip(i-j,-160,159)+160]`` and attention runs over query blocks, so
+10-minute inputs (T = 29 999; HF would need a 230 GB ``[T,T,64]`` table) stay feasible.
+
+Pinning: the reference has no tests, so parity is pinned by fixtures generated
+in the build container from the HF implementation itself (``tests/golden/make_goldens.py``) and by
+``tests/test_oracle_vs_hf.py`` which compares this file with the installed HF module directly
+wherever ``transformers`` is importable.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
+CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
+HEADS = 12
+REL_MAX = 160
+POS_CONV_K = 128
+POS_CONV_GROUPS = 16
+LN_EPS = 1e-5
+PAD_IDX = 1  # SpeechT5Config.pad_token_id; sinusoid row used for padded frames
+
+
+def _t(sd, key, dtype):
+    v = sd[key]
+    if not torch.is_tensor(v):
+        v = torch.from_numpy(v)
+    return v.to(dtype)
+
+
+def _pos_conv_keys(sd, prefix):
+    """weight-norm g, v under either spelling (4.30.2: weight_g/weight_v; 5.x: parametrizations)."""
+    if prefix + "pos_conv_embed.conv.parametrizations.weight.original0" in sd:
+        return (prefix + "pos_conv_embed.conv.parametrizations.weight.original0",
+                prefix + "pos_conv_embed.conv.parametrizations.weight.original1")
+    return prefix + "pos_conv_embed.conv.weight_g", prefix + "pos_conv_embed.conv.weight_v"
+
+
+def gelu_erf(x):
+    """exact GELU 0.5*x*(1+erf(x/sqrt(2)))  (transformers/activations.py:83-89)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def feat_extract_output_lengths(n):
+    """HF:585-598 -- floor((n-k)/s)+1 over the seven conv layers; int or LongTensor."""
+    for k, s in zip(CONV_KERNEL, CONV_STRIDE):
+        n = torch.div(n - k, s, rounding_mode="floor") + 1 if torch.is_tensor(n) else (n - k) // s + 1
+    return n
+
+
+def feature_encoder(x, sd, prefix="prenet.", dtype=torch.float32):
+    """HF:484-494, layer 0 = conv+GroupNorm(512 groups)+GELU (HF:260-281), layers 1-6 = conv+GELU
+    (HF:210-228).  x [B, L] -> [B, T, 512] (already transposed to time-major)."""
+    h = x.to(dtype)[:, None, :]
+    for i, (k, s) in enumerate(zip(CONV_KERNEL, CONV_STRIDE)):
+        w = _t(sd, f"{prefix}feature_encoder.conv_layers.{i}.conv.weight", dtype)
+        h = F.conv1d(h, w, stride=s)
+        if i == 0:
+            # GroupNorm with one group per channel: statistics over the WHOLE (padded) time axis
+            mean = h.mean(dim=2, keepdim=True)
+            var = ((h - mean) ** 2).mean(dim=2, keepdim=True)
+            gw = _t(sd, prefix + "feature_encoder.conv_layers.0.layer_norm.weight", dtype)[None, :, None]
+            gb = _t(sd, prefix + "feature_encoder.conv_layers.0.layer_norm.bias", dtype)[None, :, None]
+            h = (h - mean) * torch.rsqrt(var + LN_EPS) * gw + gb
+        h = gelu_erf(h)
+    return h.transpose(1, 2).contiguous()
+
+
+def frame_counts(attention_mask, n_frames):
+    """HF:569-582 -- valid frame count per clip from the sample mask's SUM; clamps are not applied
+    by HF either (a count of 0 would index -1; callers never pass an all-zero mask)."""
+    if attention_mask is None:
+        return None
+    lens = attention_mask.to(torch.long).sum(dim=-1)
+    return feat_extract_output_lengths(lens)
+
+
+def sinusoid_table(n_rows, dim=768, dtype=torch.float32):
+    """HF:305-321 -- row p = [sin(p*w_k) | cos(p*w_k)], w_k = exp(-k*ln(1e4)/(dim/2-1)); row PAD_IDX zeroed.
+    Always evaluated in fp32 like HF (the table is an fp32 buffer), then cast."""
+    half = dim // 2
+    w = torch.exp(torch.arange(half, dtype=torch.int64).float() * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(n_rows, dtype=torch.int64).float().unsqueeze(1) * w.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1)
+    tab[PAD_IDX] = 0
+    return tab.to(dtype)
+
+
+def pos_conv_weight(sd, prefix="prenet.", dtype=torch.float32):
+    """weight_norm(dim=2): w[o,i,k] = g[k] * v[o,i,k] / ||v[:,:,k]||  (HF:358-379, torch weight_norm)."""
+    kg, kv = _pos_conv_keys(sd, prefix)
+    g = _t(sd, kg, dtype)
+    v = _t(sd, kv, dtype)
+    norm = torch.sqrt((v * v).sum(dim=(0, 1), keepdim=True))
+    return v * (g / norm)
+
+
+def speech_prenet(x, attention_mask, sd, prefix="prenet.", dtype=torch.float32, taps=None):
+    """HF:534-566.  Returns (hidden [B,T,768], frames LongTensor[B] or None)."""
+    feats = feature_encoder(x, sd, prefix, dtype)
+    if taps is not None:
+        taps["conv_stack"] = feats
+    B, T, _ = feats.shape
+    frames = frame_counts(attention_mask, T)
+    # feature projection: LayerNorm(512) -> Linear(512,768)   (HF:498-510)
+    h = F.layer_norm(feats, (feats.shape[-1],),
+                     _t(sd, prefix + "feature_projection.layer_norm.weight", dtype),
+                     _t(sd, prefix + "feature_projection.layer_norm.bias", dtype), LN_EPS)
+    h = F.linear(h, _t(sd, prefix + "feature_projection.projection.weight", dtype),
+                 _t(sd, prefix + "feature_projection.projection.bias", dtype))
+    if taps is not None:
+        taps["feature_projection"] = h
+    # positional conv embedding: grouped conv k=128 pad=64, drop last frame, GELU; added  (HF:389-397,555-556)
+    w = pos_conv_weight(sd, prefix, dtype)
+    pc = F.conv1d(h.transpose(1, 2), w, _t(sd, prefix + "pos_conv_embed.conv.bias", dtype),
+                  padding=POS_CONV_K // 2, groups=POS_CONV_GROUPS)[:, :, :-1]
+    h = h + gelu_erf(pc).transpose(1, 2)
+    # sinusoidal positions: valid frames 2,3,...; padded frames -> row 1 (zeros)  (HF:322-351,558-564)
+    if frames is None:
+        valid = torch.ones(B, T, dtype=torch.long)
+    else:
+        valid = (torch.arange(T)[None, :] < frames[:, None]).long()
+    pos = torch.cumsum(valid, dim=1) * valid + PAD_IDX
+    tab = sinusoid_table(max(int(pos.max()) + 1, PAD_IDX + 1 + T + 2), h.shape[-1], dtype)
+    h = h + tab[pos]
+    if taps is not None:
+        taps["prenet"] = h
+    return h, frames
+
+
+def attention(x, frames, sd, lp, pe_k, dtype=torch.float32, q_block=512):
+    """HF:872-986 with the compact relative-position bias and query blocking.
+    x [B,T,768]; frames LongTensor[B] or None (keys >= frames[b] are masked for every query)."""
+    B, T, D = x.shape
+    H = HEADS
+    dh = D // H
+    q = F.linear(x, _t(sd, lp + "attention.q_proj.weight", dtype), _t(sd, lp + "attention.q_proj.bias", dtype)) * dh ** -0.5
+    k = F.linear(x, _t(sd, lp + "attention.k_proj.weight", dtype), _t(sd, lp + "attention.k_proj.bias", dtype))
+    v = F.linear(x, _t(sd, lp + "attention.v_proj.weight", dtype), _t(sd, lp + "attention.v_proj.bias", dtype))
+    q = q.view(B, T, H, dh).transpose(1, 2)  # [B,H,T,dh]
+    k = k.view(B, T, H, dh).transpose(1, 2)
+    v = v.view(B, T, H, dh).transpose(1, 2)
+    out = torch.empty(B, H, T, dh, dtype=dtype)
+    jj = torch.arange(T)
+    neg = torch.finfo(dtype).min
+    for i0 in range(0, T, q_block):
+        i1 = min(T, i0 + q_block)
+        qb = q[:, :, i0:i1]
+        s = qb @ k.transpose(-1, -2)  # [B,H,bq,T]
+        qp = qb @ pe_k.t()  # [B,H,bq,320] -- uses the already-scaled q (HF:939-945)
+        rel = (torch.arange(i0, i1)[:, None] - jj[None, :]).clamp(-REL_MAX, REL_MAX - 1) + REL_MAX
+        s = s + torch.gather(qp, 3, rel[None, None].expand(B, H, -1, -1))
+        if frames is not None:
+            masked = jj[None, :] >= frames[:, None]  # [B,T]
+            s = s + masked[:, None, None, :].to(dtype) * neg  # additive finfo.min (HF:947-953)
+        p = torch.softmax(s, dim=-1)
+        out[:, :, i0:i1] = p @ v
+    o = out.transpose(1, 2).reshape(B, T, D)
+    return F.linear(o, _t(sd, lp + "attention.out_proj.weight", dtype), _t(sd, lp + "attention.out_proj.bias", dtype))
+
+
+def encoder_layer(x, frames, sd, lp, pe_k, dtype=torch.float32, q_block=512):
+    """HF:1027-1067 post-LN: h = LN1(x + Attn(x)); y = LN2(h + FFN(h))."""
+    D = x.shape[-1]
+    h = x + attention(x, frames, sd, lp, pe_k, dtype, q_block)
+    h = F.layer_norm(h, (D,), _t(sd, lp + "layer_norm.weight", dtype), _t(sd, lp + "layer_norm.bias", dtype), LN_EPS)
+    f = F.linear(h, _t(sd, lp + "feed_forward.intermediate_dense.weight", dtype),
+                 _t(sd, lp + "feed_forward.intermediate_dense.bias", dtype))
+    f = gelu_erf(f)
+    f = F.linear(f, _t(sd, lp + "feed_forward.output_dense.weight", dtype),
+                 _t(sd, lp + "feed_forward.output_dense.bias", dtype))
+    y = h + f
+    return F.layer_norm(y, (D,), _t(sd, lp + "final_layer_norm.weight", dtype),
+                        _t(sd, lp + "final_layer_norm.bias", dtype), LN_EPS)
+
+
+def num_layers(sd, prefix="wrapped_encoder."):
+    n = 0
+    while f"{prefix}layers.{n}.layer_norm.weight" in sd:
+        n += 1
+    return n
+
+
+def wrapped_encoder(h, frames, sd, prefix="wrapped_encoder.", dtype=torch.float32, q_block=512, hidden_states=None):
+    """HF:1234-1322 (eval: dropout and LayerDrop are no-ops)."""
+    D = h.shape[-1]
+    h = F.layer_norm(h, (D,), _t(sd, prefix + "layer_norm.weight", dtype), _t(sd, prefix + "layer_norm.bias", dtype), LN_EPS)
+    pe_k = _t(sd, prefix + "embed_positions.pe_k.weight", dtype)
+    for l in range(num_layers(sd, prefix)):
+        if hidden_states is not None:
+            hidden_states.append(h)
+        h = encoder_layer(h, frames, sd, f"{prefix}layers.{l}.", pe_k, dtype, q_block)
+    if hidden_states is not None:
+        hidden_states.append(h)
+    return h
+
+
+@torch.no_grad()
+def encode(input_values, attention_mask, sd, dtype=torch.float32, q_block=512, taps=None, hidden_states=None):
+    """SpeechT5EncoderWithSpeechPrenet.forward (HF:1339-1358): waveform [B,L] (+ int mask [B,L] or
+    None) -> last_hidden_state [B,T,768].  ``sd`` holds numpy/torch tensors under the full HF key
+    names (``prenet.*`` / ``wrapped_encoder.*``)."""
+    x = torch.as_tensor(input_values)
+    m = None if attention_mask is None else torch.as_tensor(attention_mask)
+    h, frames = speech_prenet(x, m, sd, "prenet.", dtype, taps)
+    return wrapped_encoder(h, frames, sd, "wrapped_encoder.", dtype, q_block, hidden_states)

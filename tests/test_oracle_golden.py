@@ -1,0 +1,89 @@
+"""The CPU oracle against the golden fixtures generated from HuggingFace (tests/golden/make_goldens.py).
+
+This is what pins the oracle: the reference has no tests, so the committed HF
+outputs on seeded inputs are the ground truth the restatement must reproduce.  fp32 tolerance:
+relative L2 <= 5e-6 (both sides are fp32 evaluations of the same maths; observed ~8e-7).
+"""
+import numpy as np
+import torch
+
+from conftest import golden, rel_l2
+
+TOL = 5e-6
+
+
+def test_g1_one_second_full_output(oracle, synth, state_dict):
+    g = golden("g1_1s.npz")
+    x, m = synth.batch(g["lengths"])
+    taps = {}
+    y = oracle.encode(x, m, state_dict, taps=taps)
+    assert y.shape == (1, 49, 768)
+    assert rel_l2(taps["conv_stack"], g["conv_stack"]) < TOL
+    assert rel_l2(taps["prenet"], g["prenet"]) < TOL
+    assert rel_l2(y, g["last_hidden_state"]) < TOL
+
+
+def test_g2_ragged_batch_every_stage(oracle, synth, state_dict):
+    g = golden("g2_5s_3s.npz")
+    x, m = synth.batch(g["lengths"])
+    rows = g["rows"]
+    taps, hs = {}, []
+    y = oracle.encode(x, m, state_dict, taps=taps, hidden_states=hs)
+    assert y.shape == (2, 249, 768)
+    for name in ("conv_stack", "feature_projection", "prenet"):
+        assert rel_l2(taps[name][:, rows], g[name]) < TOL, name
+    assert len(hs) == 13
+    for i, h in enumerate(hs):
+        assert rel_l2(h[:, rows], g["hidden_states"][i]) < TOL, i
+        assert abs(float(h.double().norm()) / g["hidden_stats"][i, 0] - 1) < 1e-6
+    # padded frames of the short clip are NOT zero and are part of the contract (SURVEY.md §7 hard part 5)
+    assert float(y[1, 149:].abs().max()) > 0.1
+
+
+def test_g3_headline_shape_batch2(oracle, synth, state_dict):
+    g = golden("g3_30s_x2.npz")
+    x, m = synth.batch(g["lengths"])
+    hs = []
+    y = oracle.encode(x, m, state_dict, hidden_states=hs)
+    assert y.shape == (2, 1499, 768)
+    for i in (0, 1, 6, 12):
+        assert rel_l2(hs[i][:, g["rows"]], g["hidden_states"][i]) < TOL, i
+
+
+def test_g3r_ragged_30s(oracle, synth, state_dict):
+    g = golden("g3r_30s_ragged.npz")
+    assert list(g["lengths"]) == synth.mixed_lengths(3, 480000)
+    x, m = synth.batch(g["lengths"])
+    y = oracle.encode(x, m, state_dict)
+    assert rel_l2(y[:, g["rows"]], g["last_hidden_state"]) < TOL
+    assert abs(float(y.double().norm()) / g["out_stats"][0] - 1) < 1e-6
+
+
+def test_g4_attention_module_with_key_padding(oracle, synth, state_dict):
+    g = golden("g4_attention_l3.npz")
+    h = torch.from_numpy(synth.hashed_uniform("g4.hidden", (2, 200, 768), 7)) * 1.7
+    pe_k = torch.from_numpy(state_dict["wrapped_encoder.embed_positions.pe_k.weight"])
+    y = oracle.attention(h, torch.from_numpy(g["frames"]), state_dict, "wrapped_encoder.layers.3.", pe_k, q_block=64)
+    assert rel_l2(y, g["out"]) < TOL
+
+
+def test_g5_T4096_blocked_attention(oracle, synth, state_dict):
+    g = golden("g5_T4096.npz")
+    x, _ = synth.batch(g["lengths"])
+    hs = []
+    y = oracle.encode(x, None, state_dict, hidden_states=hs, q_block=256)
+    assert y.shape == (1, 4096, 768)
+    for i in (0, 1, 12):
+        assert rel_l2(hs[i][:, g["rows"]], g["hidden_states"][i]) < TOL, i
+
+
+def test_frame_counts(oracle, synth):
+    # 5 s -> 249, 30 s -> 1499, 10 min -> 29 999
+    assert oracle.feat_extract_output_lengths(80000) == 249 == synth.conv_out_length(80000)
+    assert oracle.feat_extract_output_lengths(480000) == 1499
+    assert oracle.feat_extract_output_lengths(9600000) == 29999
+    assert oracle.feat_extract_output_lengths(400) == 1
+    m = torch.zeros(2, 1000, dtype=torch.int32)
+    m[0, :1000] = 1
+    m[1, :400] = 1
+    assert oracle.frame_counts(m, 2).tolist() == [2, 1]
