@@ -1,0 +1,171 @@
+/*
+ * loco_asr.h -- C ABI of the MI355X-native SpeechT5 speech-encoder embedding path.
+ *
+ * What this boundary replaces.  The reference has no FFI of its own: its seam is a Python
+ * attribute path on a HuggingFace module,
+ *
+ *     out = model.speecht5.encoder(**audios)                      (extract_speecht5_base_embeddings_slurp.py:108,
+ *     embeddings = out.last_hidden_state                           extract_speecht5_finetuned_embeddings_slurp.py:104-106)
+ *     model.speecht5.encoder.wrapped_encoder.load_state_dict(...)  (extract_speecht5_base_embeddings_slurp.py:99)
+ *     model.speecht5.encoder.prenet.load_state_dict(...)           (extract_speecht5_base_embeddings_slurp.py:100)
+ *
+ * i.e. transformers' SpeechT5EncoderWithSpeechPrenet.forward (modeling_speecht5.py:1339-1358).  The
+ * entry points below are what a binding for that seam needs: create / load weights by their
+ * HuggingFace state-dict key / query workspace / forward on raw device pointers / destroy.  The
+ * Python host side (loco-asr_amd/encoder.py) binds them with ctypes and re-exposes the HF module
+ * contract; INTEGRATION.md shows the stub.
+ *
+ * Conventions: plain C types only; every buffer is caller-owned DEVICE memory (gfx950) unless a
+ * parameter says "host"; nothing here allocates, synchronises the host or spawns threads inside
+ * loco_forward; all work is enqueued on the hipStream_t passed in (void* so that this header needs no
+ * HIP include).  Functions returning int give 0 on success and a negative LOCO_E_* code otherwise;
+ * loco_last_error() returns the message of the calling thread's last failure.
+ */
+#ifndef LOCO_ASR_H
+#define LOCO_ASR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOCO_ABI_VERSION 1
+
+enum {
+    LOCO_OK = 0,
+    LOCO_E_INVALID = -1,   /* bad argument (shape, null pointer, unknown key) -- HF raises ValueError here */
+    LOCO_E_STATE = -2,     /* weights missing / not finalized */
+    LOCO_E_WORKSPACE = -3, /* workspace too small */
+    LOCO_E_HIP = -4        /* a HIP runtime call failed */
+};
+
+/* Model hyper-parameters = transformers SpeechT5Config defaults (configuration_speecht5.py:142-199),
+ * the configuration of "microsoft/speecht5_asr" that both reference scripts load.  Only `layers` may
+ * be lowered (tests); the kernels are specialised for the other values and loco_create rejects
+ * anything else. */
+typedef struct loco_config {
+    int32_t struct_size; /* sizeof(loco_config), for ABI checks */
+    int32_t hidden;      /* 768 */
+    int32_t heads;       /* 12  (head_dim 64) */
+    int32_t ffn;         /* 3072 */
+    int32_t layers;      /* 12 */
+    int32_t conv_dim;    /* 512; conv kernels (10,3,3,3,3,2,2), strides (5,2,2,2,2,2,2) */
+    int32_t pos_conv_kernel; /* 128 */
+    int32_t pos_conv_groups; /* 16 */
+    int32_t rel_max;     /* 160: relative positions clipped to [-160, 159] */
+    float ln_eps;        /* 1e-5 */
+} loco_config;
+
+typedef struct loco_encoder loco_encoder; /* opaque */
+
+int loco_abi_version(void);
+const char* loco_last_error(void);
+void loco_default_config(loco_config* cfg);
+
+/* Lifetime.  loco_create binds the handle to the current HIP device. */
+loco_encoder* loco_create(const loco_config* cfg);
+void loco_destroy(loco_encoder* enc);
+
+/* Weight loading -- the C side of the two load_state_dict calls.  `key` is the HuggingFace name
+ * including its sub-module prefix ("prenet.feature_encoder.conv_layers.0.conv.weight",
+ * "wrapped_encoder.layers.3.attention.q_proj.bias", ...).  Both spellings of the weight-normed
+ * positional conv are accepted (transformers 4.30.2 "...conv.weight_g/_v"; 5.x
+ * "...conv.parametrizations.weight.original0/1").  "prenet.masked_spec_embed" and
+ * "prenet.pos_sinusoidal_embed.weights" (carried by the reference's pickled dicts,
+ * map_speecht5_hf.py:164-166) are accepted; the former is unused in eval, the latter replaces the
+ * internally generated table when its row count suffices.  `data` is fp32, device or host memory
+ * (copied with hipMemcpyDefault); the library keeps its own re-laid-out copy, so the caller may free
+ * `data` on return.  Returns LOCO_E_INVALID for an unknown key or a shape mismatch. */
+int loco_set_weight(loco_encoder* enc, const char* key, const float* data, const int64_t* shape, int ndim);
+
+/* Number of tensors still missing (0 = complete); when `buf` is non-null their names are written to it,
+ * comma separated, truncated to `buflen`. */
+int loco_missing_weights(const loco_encoder* enc, char* buf, size_t buflen);
+
+/* Fold weight-norm, fuse q/k/v (+ the 1/8 query scaling), re-lay conv weights tap-major.  Must be
+ * called after the last loco_set_weight and before loco_forward; idempotent. */
+int loco_finalize_weights(loco_encoder* enc, void* stream);
+
+/* floor((n-k)/s)+1 chained over the seven conv layers (modeling_speecht5.py:585-598); <= 0 when the
+ * clip is shorter than one frame (400 samples). */
+int64_t loco_output_frames(int64_t n_samples);
+
+/* Bytes of scratch loco_forward needs for a [B, L] batch (256-byte aligned carve-outs included). */
+size_t loco_workspace_bytes(const loco_encoder* enc, int32_t B, int64_t L);
+
+/* Forward = SpeechT5EncoderWithSpeechPrenet.forward in eval mode.
+ *   wav            f32 [B, L]   zero-padded waveforms (device)
+ *   attention_mask i32 [B, L]   1 = sample present, 0 = padding (device), or NULL = all present
+ *   out            f32 [B, T, 768], T = loco_output_frames(L): last_hidden_state, padded frames included
+ *                  exactly as HF computes them (the reference pickles them, ...base...py:109-113)
+ *   out_frames     i32 [B] valid frame count per clip (device), may be NULL
+ *   hidden_states  NULL, or host array of layers+1 device pointers f32 [B,T,768] receiving the input of
+ *                  every layer and the final output (HF output_hidden_states=True, modeling:1287-1313)
+ *   workspace      >= loco_workspace_bytes(enc, B, L) bytes (device)
+ */
+int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
+                 float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
+/* Stage taps for parity tests: when set (device pointers, may individually be NULL) the next forwards also
+ * copy the conv-stack output [B,T,512], the feature projection [B,T,768] and the prenet output [B,T,768]. */
+int loco_set_taps(loco_encoder* enc, float* conv_stack, float* feature_projection, float* prenet);
+
+/* ---- per-kernel timing (bench.py's roofline leg) --------------------------------------------------
+ * With profiling on, every kernel launch inside loco_forward is bracketed by hipEvents recorded on the
+ * launch stream.  loco_profile_read synchronises those events and returns per-kernel totals since the
+ * last loco_profile_reset. */
+typedef struct loco_kernel_stat {
+    char name[48];
+    int64_t launches;
+    double ms;    /* sum of launch durations */
+    double flops; /* algorithmic FLOPs (2*MAC) of those launches */
+    double bytes; /* algorithmic bytes (compulsory reads + writes) of those launches */
+} loco_kernel_stat;
+
+int loco_set_profiling(loco_encoder* enc, int on);
+int loco_profile_reset(loco_encoder* enc);
+int loco_profile_read(loco_encoder* enc, loco_kernel_stat* stats, int max_stats); /* returns count */
+
+/* ---- single operators (used by the parity tests; same kernels loco_forward launches) --------------- */
+
+/* y[r,:] = LayerNorm(x[r,:]) * gamma + beta; dim in {512, 768}; y may alias x.  (modeling:501,1023,1025,1276) */
+int loco_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim,
+                      float eps, void* stream);
+
+/* C[z][m,n] = epi(sum_k A[z][m*lda+k] * W[n*ldw+k] + bias[n]) (+ R[z][m*ldr+n]); fp32 MFMA.
+ * epilogue: 0 = none, 1 = exact-erf GELU, 2 = add residual R.  K % 32 == 0; lda/ldw/ldc/ldr % 4 == 0.
+ * z = z1*nb2 + z2 walks nb1*nb2 problems with element strides (sA1,sA2), (sC1,sC2) (R uses C's). */
+int loco_op_gemm(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* R, int64_t ldr,
+                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2,
+                 int64_t sA1, int64_t sA2, int64_t sC1, int64_t sC2, void* stream);
+
+/* conv layer 0: Conv1d(1->512,k=10,s=5,no bias) + GroupNorm(512 groups, stats over the whole padded time
+ * axis) + GELU, channels-last output [B, T0, 512], T0 = (L-10)/5+1.  (modeling:260-281)
+ * w [512,10], gn_w/gn_b [512]; scratch >= loco_conv0_scratch_bytes(B). */
+size_t loco_conv0_scratch_bytes(int32_t B);
+int loco_op_conv0_gn_gelu(const float* wav, int32_t B, int64_t L, const float* w, const float* gn_w, const float* gn_b,
+                          float* out, void* scratch, void* stream);
+
+/* frames[b] = loco_output_frames(sum(mask[b,:])); mask NULL -> loco_output_frames(L). (modeling:569-598) */
+int loco_op_frame_counts(const int32_t* mask, int32_t B, int64_t L, int32_t* frames, void* stream);
+
+/* positional conv embedding + sinusoidal positions (modeling:389-397,555-564):
+ *   out = h + GELU(groupedconv(h) + bias) + sin_table[pos], pos = t+2 for t < frames[b] else 1.
+ * h,out [B,T,768]; w_folded [16][128][48][48] (group, tap, out, in) = weight-norm already applied;
+ * sin_table [rows,768] with rows >= T+2; frames NULL = all valid. */
+int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, const float* sin_table, const int32_t* frames,
+                     float* out, int32_t B, int32_t T, void* stream);
+
+/* self-attention core (modeling:911-982): qkv [B,T,2304] = [q*1/8 | k | v] per frame, qp [B,12,T,320] =
+ * q_scaled . pe_k^T, frames [B] or NULL; ctx [B,T,768] = softmax(q k^T + qp[i, clip(i-j)+160] + mask) v,
+ * heads merged.  Flash-style: no [T,T] tensor is ever formed. */
+int loco_op_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOCO_ASR_H */

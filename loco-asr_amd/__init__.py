@@ -1,0 +1,15 @@
+"""loco-asr_amd -- MI355X-native SpeechT5 speech-encoder embedding path of keya-dialog/LoCo-ASR.
+
+The directory name carries a hyphen (it is fixed by the build contract), so import it with
+``importlib.import_module("loco-asr_amd")`` or through the alias module ``loco_asr_amd`` at the
+repository root.  Importing the package is cheap and works without a GPU; constructing the encoder
+loads the HIP library (``libloco_asr.so``) and fails loudly if it has not been built.
+"""
+from . import synth  # noqa: F401
+from ._lib import LIB_PATH, LocoError  # noqa: F401
+from .encoder import (BaseModelOutput, SpeechT5EncoderWithSpeechPrenetMI355X,  # noqa: F401
+                      SpeechT5ForSpeechToTextMI355X, sinusoid_table)
+from .feature_extractor import BatchFeature, SpeechT5FeatureExtractorMI355X  # noqa: F401
+
+__all__ = ["synth", "LIB_PATH", "LocoError", "BaseModelOutput", "SpeechT5EncoderWithSpeechPrenetMI355X",
+           "SpeechT5ForSpeechToTextMI355X", "sinusoid_table", "BatchFeature", "SpeechT5FeatureExtractorMI355X"]

@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI declared in include/loco_asr.h.
+
+The HIP library is the product: if ``libloco_asr.so`` is missing or does not load, importing the
+encoder fails loudly here -- there is no CPU or PyTorch fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libloco_asr.so")
+ABI_VERSION = 1
+
+
+class LocoError(RuntimeError):
+    """A C-ABI call returned a negative LOCO_E_* code."""
+
+
+class LocoConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("ffn", C.c_int32),
+                ("layers", C.c_int32), ("conv_dim", C.c_int32), ("pos_conv_kernel", C.c_int32),
+                ("pos_conv_groups", C.c_int32), ("rel_max", C.c_int32), ("ln_eps", C.c_float)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_vp, _i32, _i64, _sz, _f = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); exactly the symbols of include/loco_asr.h
+SIGNATURES = {
+    "loco_abi_version": (C.c_int, []),
+    "loco_last_error": (C.c_char_p, []),
+    "loco_default_config": (None, [C.POINTER(LocoConfig)]),
+    "loco_create": (_vp, [C.POINTER(LocoConfig)]),
+    "loco_destroy": (None, [_vp]),
+    "loco_set_weight": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_i64), C.c_int]),
+    "loco_missing_weights": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "loco_finalize_weights": (C.c_int, [_vp, _vp]),
+    "loco_output_frames": (_i64, [_i64]),
+    "loco_workspace_bytes": (_sz, [_vp, _i32, _i64]),
+    "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_set_taps": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "loco_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "loco_profile_reset": (C.c_int, [_vp]),
+    "loco_profile_read": (C.c_int, [_vp, C.POINTER(KernelStat), C.c_int]),
+    "loco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f, _vp]),
+    "loco_op_gemm": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                               _i64, _i64, _i64, _i64, _vp]),
+    "loco_conv0_scratch_bytes": (_sz, [_i32]),
+    "loco_op_conv0_gn_gelu": (C.c_int, [_vp, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "loco_op_frame_counts": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
+    "loco_op_pos_conv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "loco_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libloco_asr.so once; raises (never falls back) when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library has not been built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.loco_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.loco_abi_version()} != {ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc < 0:
+        msg = load().loco_last_error().decode(errors="replace")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}" if what else msg)  # HF raises ValueError for bad shapes/masks
+        raise LocoError(f"{what}: [{rc}] {msg}" if what else f"[{rc}] {msg}")
+    return rc

@@ -1,0 +1,195 @@
+// fp32 GEMM on the CDNA4 matrix cores: C[m,n] = epi(sum_k A[m,k] * W[n,k] + bias[n]) (+ R[m,n]).
+//
+// Both operands are K-contiguous ("NT"), which is how every contraction of the SpeechT5 encoder path
+// presents itself once activations are kept time-major / channels-last:
+//   * nn.Linear            y = x W^T + b                (HF modeling_speecht5.py:502,867-870,994,1000)
+//   * Conv1d layers 1..6   out[t,n] = sum_{tap,c} X[s*t+tap, c] W[n,c,tap]: with channels-last X the row of
+//     output t is the CONTIGUOUS run X[s*t : s*t+k, :], so the conv is this GEMM with lda = s*C,
+//     K = k*C and the weight re-laid tap-major (HF modeling:216-228)
+//   * relative-position table  Qp = q_scaled pe_k^T  (compact form of HF modeling:939-945)
+//
+// Instruction: v_mfma_f32_32x32x2_f32 -- exact fp32 (bitwise an fmaf chain), 64 cycles/SIMD for 4096 FLOP,
+// chip peak 157.3 TFLOP/s.  bf16/fp16 operands miss the 1e-3 embedding tolerance (BASELINE.md precision
+// probe), gfx950 has no xf32, so fp32-in MFMA is the matrix-core path for this workload.
+//
+// Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA
+// tiles (64 accumulator VGPRs).  A/W tiles are staged global -> registers -> LDS (float4), the next
+// k-tile's global loads are issued before the current tile's MFMAs (software prefetch, two LDS buffers,
+// one barrier per k-tile).  The 32x32x2 instruction consumes k = {lane>>5}; we let lane-half h own the
+// contiguous k range [16h, 16h+16) of the tile so that fragments are read with ds_read_b128.  LDS rows
+// are padded to 36 floats: a 16-lane ds_read_b128 group then covers all 64 banks exactly once.
+//
+// Block -> tile map is XCD-aware: blocks b and b+8 share an XCD (and its private 4 MiB L2), so each XCD
+// is given a contiguous run of tiles with n fastest -- every n-tile of one A row-panel is computed on
+// the XCD that already holds that panel.
+#include "loco_kernels.h"
+
+namespace loco {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = BK + 4;  // padded LDS row (floats)
+constexpr int kGemmThreads = 256;
+
+struct TileCoord {
+    int z, mt, nt;
+};
+
+__device__ __forceinline__ TileCoord map_block(int bid, int nblk, int tiles_m, int tiles_n) {
+    // bijective XCD remap (blocks congruent mod 8 share an XCD): XCD x gets tiles [start_x, start_x + cnt_x)
+    const int q = nblk >> 3, r = nblk & 7;
+    const int x = bid & 7, i = bid >> 3;
+    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    TileCoord c;
+    c.nt = t % tiles_n;
+    const int rest = t / tiles_n;
+    c.mt = rest % tiles_m;
+    c.z = rest / tiles_m;
+    return c;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n, int nblk) {
+    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDT];
+
+    const TileCoord tc = map_block(blockIdx.x, nblk, tiles_m, tiles_n);
+    const int z1 = tc.z / p.nb2, z2 = tc.z % p.nb2;
+    const float* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
+    const float* __restrict__ W = p.W;
+    const long coff = z1 * p.sC1 + z2 * p.sC2;
+    const int m0 = tc.mt * BM, n0 = tc.nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging map: float4 index f = tid + 256*q  ->  row f/8, k4 = f%8
+    const int srow = tid >> 3, sk = (tid & 7) * 4;
+    const float* ga[4];
+    const float* gw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int ra = m0 + srow + 32 * q;
+        ra = ra < p.M ? ra : p.M - 1;  // clamp: rows past M are computed on valid data and never stored
+        int rw = n0 + srow + 32 * q;
+        rw = rw < p.N ? rw : p.N - 1;
+        ga[q] = A + (long)ra * p.lda + sk;
+        gw[q] = W + (long)rw * p.ldw + sk;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra4[4], rw4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ra4[q] = *reinterpret_cast<const f32x4*>(ga[q]);
+        rw4[q] = *reinterpret_cast<const f32x4*>(gw[q]);
+    }
+    {
+        float* la = lds[0];
+        float* lw = lds[0] + BM * LDT;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<f32x4*>(la + (srow + 32 * q) * LDT + sk) = ra4[q];
+            *reinterpret_cast<f32x4*>(lw + (srow + 32 * q) * LDT + sk) = rw4[q];
+        }
+    }
+    __syncthreads();
+
+    const int nk = p.K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                ra4[q] = *reinterpret_cast<const f32x4*>(ga[q] + (long)(kt + 1) * BK);
+                rw4[q] = *reinterpret_cast<const f32x4*>(gw[q] + (long)(kt + 1) * BK);
+            }
+        }
+        const float* la = lds[cur] + (wm * 64 + r) * LDT + 16 * h;
+        const float* lw = lds[cur] + (BM + wn * 64 + r) * LDT + 16 * h;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(la + k4 * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(la + 32 * LDT + k4 * 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lw + k4 * 4);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(lw + 32 * LDT + k4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float* na = lds[cur ^ 1];
+            float* nw = lds[cur ^ 1] + BM * LDT;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<f32x4*>(na + (srow + 32 * q) * LDT + sk) = ra4[q];
+                *reinterpret_cast<f32x4*>(nw + (srow + 32 * q) * LDT + sk) = rw4[q];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*h][col = r] of the 32x32 sub-tile
+    float* __restrict__ C = p.C + coff;
+    const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + r;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int mb = m0 + wm * 64 + i * 32 + 4 * h;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                if (m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    if (EPI == kEpiGelu) v = gelu_erf(v);
+                    if (EPI == kEpiResidual) v += R[(long)m * p.ldr + n];
+                    C[(long)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % BK != 0) return hipErrorInvalidValue;
+    if ((a.lda | a.ldw | a.sA1 | a.sA2) & 3) return hipErrorInvalidValue;  // float4 staging
+    if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return hipErrorInvalidValue;
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const long nblk = (long)tiles_m * tiles_n * a.nb1 * a.nb2;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk), block(kGemmThreads);
+    switch (a.epilogue) {
+        case kEpiNone:
+            hipLaunchKernelGGL(gemm_f32_kernel<kEpiNone>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            break;
+        case kEpiGelu:
+            hipLaunchKernelGGL(gemm_f32_kernel<kEpiGelu>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            break;
+        case kEpiResidual:
+            if (!a.R) return hipErrorInvalidValue;
+            hipLaunchKernelGGL(gemm_f32_kernel<kEpiResidual>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            break;
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace loco

@@ -1,0 +1,659 @@
+// C ABI (include/loco_asr.h) and the host-side orchestration of the encoder forward.
+//
+// One forward = SpeechT5EncoderWithSpeechPrenet.forward in eval mode (HF modeling_speecht5.py:1339-1358):
+//   prenet (HF :534-566): conv0+GroupNorm+GELU -> 6 x (conv as GEMM + GELU) -> LayerNorm(512) -> Linear(512,768)
+//                         -> + GELU(pos-conv) + sinusoid
+//   encoder (HF :1234-1322): LayerNorm(768) -> 12 x [ fused QKV GEMM, Qp GEMM, flash attention, out-proj GEMM(+x),
+//                            LayerNorm, FFN1 GEMM(+GELU), FFN2 GEMM(+h), LayerNorm ]
+// Everything is enqueued on the caller's stream from a caller-owned workspace; no allocation, host
+// synchronisation or thread is used inside loco_forward (the one exception, growing the sinusoid table
+// past its reserved rows, mirrors HF's own auto-grow at modeling:331-333 and is done before any launch).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/loco_asr.h"
+#include "loco_kernels.h"
+
+using namespace loco;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(LOCO_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Tensor {
+    float* d = nullptr;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+const int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
+const int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
+
+struct LayerW {
+    float* wqkv = nullptr;  // [2304,768], q rows pre-scaled by 1/8
+    float* bqkv = nullptr;  // [2304]
+};
+
+enum KernelId { K_GEMM = 0, K_ATTN, K_LN, K_CONV0, K_POSCONV, K_FRAMES, K_COPY, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"gemm_f32",     "attention_f32", "layernorm", "conv0_gn_gelu",
+                                           "pos_conv_f32", "frame_counts",  "copy"};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int kid;
+    double flops, bytes;
+};
+
+}  // namespace
+
+struct loco_encoder {
+    loco_config cfg;
+    int device = 0;
+    std::map<std::string, Tensor> raw;  // as loaded, HF names
+    std::map<std::string, std::vector<int64_t>> expected;
+    bool finalized = false;
+    // prepared
+    float* conv_w[7] = {nullptr};  // [512, k*512] tap-major (layer 0 stays [512,10])
+    float* pos_w = nullptr;        // [16][128][48][48]
+    std::vector<LayerW> layers;
+    float* sin_tab = nullptr;
+    int sin_rows = 0;
+    bool sin_user = false;
+    // taps
+    float *tap_conv = nullptr, *tap_proj = nullptr, *tap_prenet = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRec> recs;
+    size_t recs_used = 0;
+    loco_kernel_stat stats[K_COUNT];
+};
+
+namespace {
+
+void build_expected(loco_encoder* e) {
+    auto& x = e->expected;
+    const int64_t H = e->cfg.hidden, C = e->cfg.conv_dim, F = e->cfg.ffn;
+    const std::string p = "prenet.";
+    x[p + "masked_spec_embed"] = {H};
+    for (int i = 0; i < 7; ++i)
+        x[p + "feature_encoder.conv_layers." + std::to_string(i) + ".conv.weight"] = {C, i == 0 ? 1 : C, kConvK[i]};
+    x[p + "feature_encoder.conv_layers.0.layer_norm.weight"] = {C};
+    x[p + "feature_encoder.conv_layers.0.layer_norm.bias"] = {C};
+    x[p + "feature_projection.layer_norm.weight"] = {C};
+    x[p + "feature_projection.layer_norm.bias"] = {C};
+    x[p + "feature_projection.projection.weight"] = {H, C};
+    x[p + "feature_projection.projection.bias"] = {H};
+    x[p + "pos_conv_embed.conv.bias"] = {H};
+    x[p + "pos_conv_embed.conv.parametrizations.weight.original0"] = {1, 1, e->cfg.pos_conv_kernel};
+    x[p + "pos_conv_embed.conv.parametrizations.weight.original1"] = {H, H / e->cfg.pos_conv_groups, e->cfg.pos_conv_kernel};
+    const std::string w = "wrapped_encoder.";
+    x[w + "layer_norm.weight"] = {H};
+    x[w + "layer_norm.bias"] = {H};
+    x[w + "embed_positions.pe_k.weight"] = {2 * e->cfg.rel_max, H / e->cfg.heads};
+    for (int l = 0; l < e->cfg.layers; ++l) {
+        const std::string b = w + "layers." + std::to_string(l) + ".";
+        for (const char* pr : {"q_proj", "k_proj", "v_proj", "out_proj"}) {
+            x[b + "attention." + pr + ".weight"] = {H, H};
+            x[b + "attention." + pr + ".bias"] = {H};
+        }
+        for (const char* ln : {"layer_norm", "final_layer_norm"}) {
+            x[b + ln + ".weight"] = {H};
+            x[b + ln + ".bias"] = {H};
+        }
+        x[b + "feed_forward.intermediate_dense.weight"] = {F, H};
+        x[b + "feed_forward.intermediate_dense.bias"] = {F};
+        x[b + "feed_forward.output_dense.weight"] = {H, F};
+        x[b + "feed_forward.output_dense.bias"] = {H};
+    }
+}
+
+bool optional_key(const std::string& k) { return k == "prenet.masked_spec_embed"; }
+
+std::string canonical_key(const char* key) {
+    std::string k(key);
+    const std::string a = "pos_conv_embed.conv.weight_g", b = "pos_conv_embed.conv.weight_v";
+    size_t pos;
+    if ((pos = k.find(a)) != std::string::npos && pos + a.size() == k.size())
+        k.replace(pos, a.size(), "pos_conv_embed.conv.parametrizations.weight.original0");
+    else if ((pos = k.find(b)) != std::string::npos && pos + b.size() == k.size())
+        k.replace(pos, b.size(), "pos_conv_embed.conv.parametrizations.weight.original1");
+    return k;
+}
+
+const float* W(const loco_encoder* e, const std::string& k) { return e->raw.at(k).d; }
+
+size_t align_up(size_t n) { return (n + 255) & ~size_t(255); }
+
+struct Plan {
+    int B;
+    long L;
+    long Tc[7];  // conv output lengths
+    long T, M;
+    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, total;
+};
+
+bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
+    p.B = B;
+    p.L = L;
+    long n = L;
+    for (int i = 0; i < 7; ++i) {
+        n = conv_out_len(n, kConvK[i], kConvS[i]);
+        p.Tc[i] = n;
+    }
+    if (B <= 0 || n <= 0) return false;
+    p.T = n;
+    p.M = (long)B * n;
+    const size_t f = sizeof(float);
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o += align_up(bytes);
+        return at;
+    };
+    p.off_frames = take((size_t)B * sizeof(int32_t));
+    p.off_c0scratch = take(conv0_scratch_bytes(B));
+    p.off_a = take((size_t)B * p.Tc[0] * kConvDim * f);
+    p.off_b = take((size_t)B * p.Tc[1] * kConvDim * f);
+    p.off_x0 = take((size_t)p.M * kHidden * f);
+    p.off_x1 = take((size_t)p.M * kHidden * f);
+    p.off_tmp = take((size_t)p.M * kHidden * f);
+    p.off_ctx = take((size_t)p.M * kHidden * f);
+    p.off_qkv = take((size_t)p.M * kQkv * f);
+    p.off_qp = take((size_t)p.M * kHeads * kRelN * f);
+    p.off_ffn = take((size_t)p.M * e->cfg.ffn * f);
+    p.total = o;
+    return true;
+}
+
+// ---- profiling brackets -----------------------------------------------------------------------------
+struct Bracket {
+    loco_encoder* e;
+    hipStream_t s;
+    ProfRec* rec = nullptr;
+    Bracket(loco_encoder* enc, hipStream_t st, int kid, double flops, double bytes) : e(enc), s(st) {
+        if (!e->profiling) return;
+        if (e->recs_used == e->recs.size()) {
+            ProfRec r{};
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+            e->recs.push_back(r);
+        }
+        rec = &e->recs[e->recs_used++];
+        rec->kid = kid;
+        rec->flops = flops;
+        rec->bytes = bytes;
+        (void)hipEventRecord(rec->a, s);
+    }
+    ~Bracket() {
+        if (rec) (void)hipEventRecord(rec->b, s);
+    }
+};
+
+int run_gemm(loco_encoder* e, hipStream_t s, const float* A, long lda, const float* Wt, long ldw, const float* bias,
+             const float* R, long ldr, float* C, long ldc, int M, int N, int K, int epi, int nb1 = 1, int nb2 = 1,
+             long sA1 = 0, long sA2 = 0, long sC1 = 0, long sC2 = 0) {
+    GemmArgs a{A, Wt, bias, R, C, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epi};
+    const double nb = (double)nb1 * nb2;
+    const double flops = 2.0 * M * (double)N * K * nb;
+    const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
+    Bracket br(e, s, K_GEMM, flops, bytes);
+    HIP_TRY(launch_gemm(a, s));
+    return LOCO_OK;
+}
+
+int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const float* b, float* y, long rows, int dim) {
+    Bracket br(e, s, K_LN, 8.0 * rows * dim, 8.0 * rows * dim);
+    HIP_TRY(launch_layernorm(x, g, b, y, rows, dim, e->cfg.ln_eps, s));
+    return LOCO_OK;
+}
+
+int run_copy(loco_encoder* e, hipStream_t s, float* dst, const float* src, size_t n) {
+    Bracket br(e, s, K_COPY, 0.0, 8.0 * n);
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return LOCO_OK;
+}
+
+int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s) {
+    if (e->sin_rows >= rows) return LOCO_OK;
+    // grow (HF does the same on demand, modeling:331-333); happens once per new maximum length
+    int want = rows < 4002 ? 4002 : rows + 2;
+    float* nt = nullptr;
+    HIP_TRY(hipMalloc(&nt, (size_t)want * kHidden * sizeof(float)));
+    hipError_t err = launch_sinusoid_table(nt, want, s);
+    if (err != hipSuccess) {
+        (void)hipFree(nt);
+        return fail(LOCO_E_HIP, "sinusoid table: %s", hipGetErrorString(err));
+    }
+    if (e->sin_tab) {
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(e->sin_tab);
+    }
+    e->sin_tab = nt;
+    e->sin_rows = want;
+    e->sin_user = false;
+    return LOCO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int loco_abi_version(void) { return LOCO_ABI_VERSION; }
+
+const char* loco_last_error(void) { return g_err.c_str(); }
+
+void loco_default_config(loco_config* c) {
+    if (!c) return;
+    c->struct_size = (int32_t)sizeof(loco_config);
+    c->hidden = kHidden;
+    c->heads = kHeads;
+    c->ffn = kFfn;
+    c->layers = 12;
+    c->conv_dim = kConvDim;
+    c->pos_conv_kernel = kPosK;
+    c->pos_conv_groups = kPosGroups;
+    c->rel_max = kRelMax;
+    c->ln_eps = 1e-5f;
+}
+
+loco_encoder* loco_create(const loco_config* cfg) {
+    loco_config c;
+    loco_default_config(&c);
+    if (cfg) {
+        if (cfg->struct_size != (int32_t)sizeof(loco_config)) {
+            fail(LOCO_E_INVALID, "loco_config.struct_size %d != %zu", cfg->struct_size, sizeof(loco_config));
+            return nullptr;
+        }
+        c = *cfg;
+    }
+    if (c.hidden != kHidden || c.heads != kHeads || c.ffn != kFfn || c.conv_dim != kConvDim ||
+        c.pos_conv_kernel != kPosK || c.pos_conv_groups != kPosGroups || c.rel_max != kRelMax || c.layers < 0 ||
+        c.layers > 64) {
+        fail(LOCO_E_INVALID, "unsupported configuration: kernels are specialised for SpeechT5-base (768/12/3072/512/128/16/160)");
+        return nullptr;
+    }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        fail(LOCO_E_HIP, "hipGetDevice failed: no usable HIP device");
+        return nullptr;
+    }
+    loco_encoder* e = new loco_encoder();
+    e->cfg = c;
+    e->device = dev;
+    e->layers.resize(c.layers);
+    build_expected(e);
+    for (int i = 0; i < K_COUNT; ++i) {
+        memset(&e->stats[i], 0, sizeof(loco_kernel_stat));
+        snprintf(e->stats[i].name, sizeof e->stats[i].name, "%s", kKernelNames[i]);
+    }
+    return e;
+}
+
+void loco_destroy(loco_encoder* e) {
+    if (!e) return;
+    for (auto& kv : e->raw) (void)hipFree(kv.second.d);
+    for (int i = 1; i < 7; ++i) (void)hipFree(e->conv_w[i]);
+    (void)hipFree(e->pos_w);
+    for (auto& l : e->layers) {
+        (void)hipFree(l.wqkv);
+        (void)hipFree(l.bqkv);
+    }
+    (void)hipFree(e->sin_tab);
+    for (auto& r : e->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    delete e;
+}
+
+int loco_set_weight(loco_encoder* e, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!e || !key || !data || !shape || ndim < 1 || ndim > 4) return fail(LOCO_E_INVALID, "loco_set_weight: null/invalid argument");
+    const std::string k = canonical_key(key);
+    std::vector<int64_t> shp(shape, shape + ndim);
+    int64_t n = 1;
+    for (auto s : shp) n *= s;
+    if (k == "prenet.pos_sinusoidal_embed.weights") {
+        if (ndim != 2 || shp[1] != kHidden || shp[0] < 3) return fail(LOCO_E_INVALID, "%s: expected [rows,768]", key);
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)n * sizeof(float)));
+        HIP_TRY(hipMemcpy(d, data, (size_t)n * sizeof(float), hipMemcpyDefault));
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(e->sin_tab);
+        e->sin_tab = d;
+        e->sin_rows = (int)shp[0];
+        e->sin_user = true;
+        return LOCO_OK;
+    }
+    auto it = e->expected.find(k);
+    if (it == e->expected.end()) return fail(LOCO_E_INVALID, "unexpected key in state_dict: %s", key);
+    if (it->second != shp) {
+        std::string got, want;
+        for (auto s : shp) got += std::to_string(s) + ",";
+        for (auto s : it->second) want += std::to_string(s) + ",";
+        return fail(LOCO_E_INVALID, "size mismatch for %s: got [%s] expected [%s]", key, got.c_str(), want.c_str());
+    }
+    Tensor& t = e->raw[k];
+    if (!t.d) HIP_TRY(hipMalloc(&t.d, (size_t)n * sizeof(float)));
+    t.shape = shp;
+    HIP_TRY(hipMemcpy(t.d, data, (size_t)n * sizeof(float), hipMemcpyDefault));
+    e->finalized = false;
+    return LOCO_OK;
+}
+
+int loco_missing_weights(const loco_encoder* e, char* buf, size_t buflen) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    int missing = 0;
+    std::string names;
+    for (auto& kv : e->expected) {
+        if (optional_key(kv.first) || e->raw.count(kv.first)) continue;
+        ++missing;
+        if (!names.empty()) names += ",";
+        names += kv.first;
+    }
+    if (buf && buflen) snprintf(buf, buflen, "%s", names.c_str());
+    return missing;
+}
+
+int loco_finalize_weights(loco_encoder* e, void* stream) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    hipStream_t s = (hipStream_t)stream;
+    char names[256];
+    const int miss = loco_missing_weights(e, names, sizeof names);
+    if (miss) return fail(LOCO_E_STATE, "%d weights missing: %s", miss, names);
+    const std::string p = "prenet.", w = "wrapped_encoder.";
+    // conv layers 1..6: [512,512,k] -> [512, k*512]
+    for (int i = 1; i < 7; ++i) {
+        const size_t n = (size_t)kConvDim * kConvDim * kConvK[i];
+        if (!e->conv_w[i]) HIP_TRY(hipMalloc(&e->conv_w[i], n * sizeof(float)));
+        HIP_TRY(launch_relayout_conv_weight(W(e, p + "feature_encoder.conv_layers." + std::to_string(i) + ".conv.weight"),
+                                            e->conv_w[i], kConvDim, kConvDim, kConvK[i], s));
+    }
+    e->conv_w[0] = e->raw.at(p + "feature_encoder.conv_layers.0.conv.weight").d;
+    // positional conv: fold weight-norm, lay out [group][tap][o][i]
+    if (!e->pos_w) HIP_TRY(hipMalloc(&e->pos_w, (size_t)kHidden * kPosCg * kPosK * sizeof(float)));
+    HIP_TRY(launch_fold_pos_conv(W(e, p + "pos_conv_embed.conv.parametrizations.weight.original0"),
+                                 W(e, p + "pos_conv_embed.conv.parametrizations.weight.original1"), e->pos_w, s));
+    // fused QKV with the 1/8 query scaling folded in: (x Wq^T + bq)/8 == x (Wq/8)^T + bq/8 exactly (power of two)
+    const size_t hh = (size_t)kHidden * kHidden;
+    for (int l = 0; l < e->cfg.layers; ++l) {
+        LayerW& lw = e->layers[l];
+        const std::string b = w + "layers." + std::to_string(l) + ".attention.";
+        if (!lw.wqkv) HIP_TRY(hipMalloc(&lw.wqkv, 3 * hh * sizeof(float)));
+        if (!lw.bqkv) HIP_TRY(hipMalloc(&lw.bqkv, 3 * kHidden * sizeof(float)));
+        HIP_TRY(launch_scale_copy(W(e, b + "q_proj.weight"), lw.wqkv, hh, 0.125f, s));
+        HIP_TRY(launch_scale_copy(W(e, b + "k_proj.weight"), lw.wqkv + hh, hh, 1.0f, s));
+        HIP_TRY(launch_scale_copy(W(e, b + "v_proj.weight"), lw.wqkv + 2 * hh, hh, 1.0f, s));
+        HIP_TRY(launch_scale_copy(W(e, b + "q_proj.bias"), lw.bqkv, kHidden, 0.125f, s));
+        HIP_TRY(launch_scale_copy(W(e, b + "k_proj.bias"), lw.bqkv + kHidden, kHidden, 1.0f, s));
+        HIP_TRY(launch_scale_copy(W(e, b + "v_proj.bias"), lw.bqkv + 2 * kHidden, kHidden, 1.0f, s));
+    }
+    int rc = ensure_sin_rows(e, 4002, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    e->finalized = true;
+    return LOCO_OK;
+}
+
+int64_t loco_output_frames(int64_t n) {
+    for (int i = 0; i < 7; ++i) {
+        const int64_t d = n - kConvK[i];
+        n = (d >= 0 ? d / kConvS[i] : -((-d + kConvS[i] - 1) / kConvS[i])) + 1;
+    }
+    return n;
+}
+
+size_t loco_workspace_bytes(const loco_encoder* e, int32_t B, int64_t L) {
+    Plan p;
+    if (!e || !make_plan(e, B, L, p)) return 0;
+    return p.total;
+}
+
+int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection, float* prenet) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    e->tap_conv = conv_stack;
+    e->tap_proj = feature_projection;
+    e->tap_prenet = prenet;
+    return LOCO_OK;
+}
+
+int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
+                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !wav || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward: null argument");
+    if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
+    Plan p;
+    if (!make_plan(e, B, L, p))
+        return fail(LOCO_E_INVALID, "loco_forward: batch %d x %lld samples gives no output frame (need >= 400 samples)", B, (long long)L);
+    if (B > 65535) return fail(LOCO_E_INVALID, "loco_forward: batch %d > 65535", B);
+    if (p.M > 0x7fffffffL / 8) return fail(LOCO_E_INVALID, "loco_forward: B*T = %ld frames is too large", p.M);
+    if (workspace_bytes < p.total)
+        return fail(LOCO_E_WORKSPACE, "loco_forward: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(wav) & 3))
+        return fail(LOCO_E_INVALID, "loco_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_sin_rows(e, (int)p.T + 2, s);
+    if (rc) return rc;
+
+    char* ws = reinterpret_cast<char*>(workspace);
+    int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
+    float* bufA = reinterpret_cast<float*>(ws + p.off_a);
+    float* bufB = reinterpret_cast<float*>(ws + p.off_b);
+    float* x0 = reinterpret_cast<float*>(ws + p.off_x0);
+    float* x1 = reinterpret_cast<float*>(ws + p.off_x1);
+    float* tmp = reinterpret_cast<float*>(ws + p.off_tmp);
+    float* ctx = reinterpret_cast<float*>(ws + p.off_ctx);
+    float* qkv = reinterpret_cast<float*>(ws + p.off_qkv);
+    float* qp = reinterpret_cast<float*>(ws + p.off_qp);
+    float* ffn = reinterpret_cast<float*>(ws + p.off_ffn);
+    const std::string pn = "prenet.", we = "wrapped_encoder.";
+    const int T = (int)p.T;
+    const long M = p.M;
+
+    // ---- valid frame counts (HF :569-598)
+    {
+        Bracket br(e, s, K_FRAMES, 0.0, mask ? 4.0 * B * (double)L : 0.0);
+        HIP_TRY(launch_frame_counts(mask, B, L, frames, s));
+    }
+    const int32_t* frames_or_null = mask ? frames : nullptr;
+
+    // ---- feature encoder (HF :484-494)
+    {
+        const double outb = 4.0 * B * (double)p.Tc[0] * kConvDim;
+        Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
+        HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
+                                     W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), bufA,
+                                     ws + p.off_c0scratch, e->cfg.ln_eps, s));
+    }
+    float* cin = bufA;
+    float* cout = bufB;
+    for (int i = 1; i < 7; ++i) {
+        const long Tin = p.Tc[i - 1], Tout = p.Tc[i];
+        rc = run_gemm(e, s, cin, (long)kConvS[i] * kConvDim, e->conv_w[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
+                      cout, kConvDim, (int)Tout, kConvDim, kConvK[i] * kConvDim, kEpiGelu, B, 1, Tin * kConvDim, 0,
+                      Tout * kConvDim, 0);
+        if (rc) return rc;
+        float* t = cin;
+        cin = cout;
+        cout = t;
+    }
+    float* feats = cin;  // [M,512]
+    if (e->tap_conv && (rc = run_copy(e, s, e->tap_conv, feats, (size_t)M * kConvDim))) return rc;
+
+    // ---- feature projection (HF :498-510): LayerNorm(512) in place, then Linear(512,768)
+    if ((rc = run_ln(e, s, feats, W(e, pn + "feature_projection.layer_norm.weight"),
+                     W(e, pn + "feature_projection.layer_norm.bias"), feats, M, kConvDim)))
+        return rc;
+    if ((rc = run_gemm(e, s, feats, kConvDim, W(e, pn + "feature_projection.projection.weight"), kConvDim,
+                       W(e, pn + "feature_projection.projection.bias"), nullptr, 0, x1, kHidden, (int)M, kHidden, kConvDim,
+                       kEpiNone)))
+        return rc;
+    if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
+
+    // ---- positional conv + sinusoid (HF :555-564)
+    {
+        Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
+        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
+    }
+    if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
+
+    // ---- encoder (HF :1276-1304)
+    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden))) return rc;
+    const float* pe_k = W(e, we + "embed_positions.pe_k.weight");
+    const int nl = e->cfg.layers;
+    for (int l = 0; l < nl; ++l) {
+        if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
+        const std::string b = we + "layers." + std::to_string(l) + ".";
+        const LayerW& lw = e->layers[l];
+        // fused q|k|v projection, q pre-scaled (HF :891,911-914)
+        if ((rc = run_gemm(e, s, x0, kHidden, lw.wqkv, kHidden, lw.bqkv, nullptr, 0, qkv, kQkv, (int)M, kQkv, kHidden, kEpiNone)))
+            return rc;
+        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T  -> [B,12,T,320]
+        if ((rc = run_gemm(e, s, qkv, kQkv, pe_k, kHeadDim, nullptr, nullptr, 0, qp, kRelN, T, kRelN, kHeadDim, kEpiNone, B,
+                           kHeads, (long)T * kQkv, kHeadDim, (long)kHeads * T * kRelN, (long)T * kRelN)))
+            return rc;
+        {
+            const double tt = (double)T * T;
+            Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
+            HIP_TRY(launch_attention(qkv, qp, frames_or_null, ctx, B, T, s));
+        }
+        // out_proj + residual (HF :984,1056), LayerNorm (HF :1058)
+        if ((rc = run_gemm(e, s, ctx, kHidden, W(e, b + "attention.out_proj.weight"), kHidden, W(e, b + "attention.out_proj.bias"),
+                           x0, kHidden, tmp, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
+            return rc;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), x1, M, kHidden))) return rc;
+        // FFN (HF :1003-1010) + residual + final LayerNorm (HF :1059-1060)
+        if ((rc = run_gemm(e, s, x1, kHidden, W(e, b + "feed_forward.intermediate_dense.weight"), kHidden,
+                           W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0, ffn, e->cfg.ffn, (int)M, e->cfg.ffn,
+                           kHidden, kEpiGelu)))
+            return rc;
+        if ((rc = run_gemm(e, s, ffn, e->cfg.ffn, W(e, b + "feed_forward.output_dense.weight"), e->cfg.ffn,
+                           W(e, b + "feed_forward.output_dense.bias"), x1, kHidden, tmp, kHidden, (int)M, kHidden, e->cfg.ffn,
+                           kEpiResidual)))
+            return rc;
+        float* dst = (l == nl - 1) ? out : x0;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"), dst, M, kHidden)))
+            return rc;
+    }
+    if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
+    if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
+    return LOCO_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------------
+int loco_set_profiling(loco_encoder* e, int on) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    e->profiling = on != 0;
+    return LOCO_OK;
+}
+
+static int drain_records(loco_encoder* e) {
+    for (size_t i = 0; i < e->recs_used; ++i) {
+        ProfRec& r = e->recs[i];
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        loco_kernel_stat& st = e->stats[r.kid];
+        st.launches += 1;
+        st.ms += ms;
+        st.flops += r.flops;
+        st.bytes += r.bytes;
+    }
+    e->recs_used = 0;
+    return LOCO_OK;
+}
+
+int loco_profile_reset(loco_encoder* e) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    int rc = drain_records(e);
+    if (rc) return rc;
+    for (int i = 0; i < K_COUNT; ++i) {
+        e->stats[i].launches = 0;
+        e->stats[i].ms = e->stats[i].flops = e->stats[i].bytes = 0.0;
+    }
+    return LOCO_OK;
+}
+
+int loco_profile_read(loco_encoder* e, loco_kernel_stat* stats, int max_stats) {
+    if (!e || !stats) return fail(LOCO_E_INVALID, "null argument");
+    int rc = drain_records(e);
+    if (rc) return rc;
+    int n = 0;
+    for (int i = 0; i < K_COUNT && n < max_stats; ++i)
+        if (e->stats[i].launches) stats[n++] = e->stats[i];
+    return n;
+}
+
+// ---- single operators ------------------------------------------------------------------------------------
+int loco_op_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int32_t dim, float eps,
+                      void* stream) {
+    if (!x || !gamma || !beta || !y) return fail(LOCO_E_INVALID, "loco_op_layernorm: null argument");
+    if (dim != 512 && dim != 768) return fail(LOCO_E_INVALID, "loco_op_layernorm: dim %d not in {512,768}", dim);
+    HIP_TRY(launch_layernorm(x, gamma, beta, y, rows, dim, eps, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* R, int64_t ldr,
+                 float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2,
+                 int64_t sA1, int64_t sA2, int64_t sC1, int64_t sC2, void* stream) {
+    if (!A || !Wt || !C) return fail(LOCO_E_INVALID, "loco_op_gemm: null argument");
+    if (K % 32 || (lda | ldw) & 3) return fail(LOCO_E_INVALID, "loco_op_gemm: K %% 32 and lda/ldw %% 4 must be 0");
+    if (nb1 < 1 || nb2 < 1) return fail(LOCO_E_INVALID, "loco_op_gemm: batch counts must be >= 1");
+    GemmArgs a{A, Wt, bias, R, C, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epilogue};
+    HIP_TRY(launch_gemm(a, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+size_t loco_conv0_scratch_bytes(int32_t B) { return conv0_scratch_bytes(B); }
+
+int loco_op_conv0_gn_gelu(const float* wav, int32_t B, int64_t L, const float* w, const float* gn_w, const float* gn_b,
+                          float* out, void* scratch, void* stream) {
+    if (!wav || !w || !gn_w || !gn_b || !out || !scratch) return fail(LOCO_E_INVALID, "loco_op_conv0_gn_gelu: null argument");
+    if (L < 10) return fail(LOCO_E_INVALID, "loco_op_conv0_gn_gelu: L < 10");
+    HIP_TRY(launch_conv0_gn_gelu(wav, B, L, w, gn_w, gn_b, out, scratch, 1e-5f, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_frame_counts(const int32_t* mask, int32_t B, int64_t L, int32_t* frames, void* stream) {
+    if (!frames || B <= 0) return fail(LOCO_E_INVALID, "loco_op_frame_counts: invalid argument");
+    HIP_TRY(launch_frame_counts(mask, B, L, frames, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, const float* sin_table, const int32_t* frames,
+                     float* out, int32_t B, int32_t T, void* stream) {
+    if (!h || !w_folded || !bias || !sin_table || !out) return fail(LOCO_E_INVALID, "loco_op_pos_conv: null argument");
+    HIP_TRY(launch_pos_conv(h, w_folded, bias, sin_table, frames, out, B, T, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T, void* stream) {
+    if (!qkv || !qp || !ctx) return fail(LOCO_E_INVALID, "loco_op_attention: null argument");
+    HIP_TRY(launch_attention(qkv, qp, frames, ctx, B, T, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+}  // extern "C"

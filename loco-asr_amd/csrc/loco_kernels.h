@@ -1,0 +1,65 @@
+// Internal launcher declarations shared by the kernel translation units and the C-ABI (loco_api.hip).
+// gfx950 only: 64-lane wavefronts, fp32-input MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace loco {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHidden = 768;
+constexpr int kHeads = 12;
+constexpr int kHeadDim = 64;
+constexpr int kFfn = 3072;
+constexpr int kConvDim = 512;
+constexpr int kPosK = 128;
+constexpr int kPosGroups = 16;
+constexpr int kPosCg = 48;  // channels per group
+constexpr int kRelMax = 160;
+constexpr int kRelN = 320;
+constexpr int kQkv = 3 * kHidden;
+
+enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2 };
+
+struct GemmArgs {
+    const float* A;
+    const float* W;
+    const float* bias;  // may be null
+    const float* R;     // residual (kEpiResidual), same batch strides as C
+    float* C;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    int nb1, nb2;
+    long sA1, sA2, sC1, sC2;
+    int epilogue;
+};
+
+// exact GELU 0.5*x*(1+erf(x/sqrt2))
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
+                            hipStream_t s);
+
+constexpr int kConv0Parts = 64;    // partial-moment blocks per clip
+constexpr int kConv0Moments = 65;  // 10 first + 55 second moments
+size_t conv0_scratch_bytes(int B);
+hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
+                                float* out, void* scratch, float eps, hipStream_t s);
+hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
+hipError_t launch_pos_conv(const float* h, const float* wf, const float* bias, const float* sin_table,
+                           const int32_t* frames, float* out, int B, int T, hipStream_t s);
+hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,
+                            hipStream_t s);
+
+// weight preparation (run once in loco_finalize_weights)
+hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C, int k, hipStream_t s);  // [N,C,k]->[N,k*C]
+hipError_t launch_fold_pos_conv(const float* g, const float* v, float* out, hipStream_t s);  // -> [16][128][48][48]
+hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
+hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s);
+
+inline long conv_out_len(long n, int k, int s) { return n < k ? 0 : (n - k) / s + 1; }
+
+}  // namespace loco

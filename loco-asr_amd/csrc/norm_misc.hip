@@ -1,0 +1,177 @@
+// LayerNorm (one 64-lane wavefront per row, shuffle reductions), frame counts, weight preparation and
+// the sinusoidal position table.  All HBM-bound byte movers: float4 accesses, no LDS.
+#include "loco_kernels.h"
+
+namespace loco {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance, two-pass over registers
+// (HF nn.LayerNorm sites: modeling_speecht5.py:501,1023,1025,1276).  NV4 = dim / 256.
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float* __restrict__ y, long rows,
+                                                        float eps) {
+    constexpr int D = NV4 * 256;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    float4 v[NV4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        v[i] = xr[lane + 64 * i];
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    float4* yr = reinterpret_cast<float4*>(y + row * D);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+        const float4 gg = reinterpret_cast<const float4*>(g)[lane + 64 * i];
+        const float4 bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
+        float4 o;
+        o.x = v[i].x * rstd * gg.x + bb.x;
+        o.y = v[i].y * rstd * gg.y + bb.y;
+        o.z = v[i].z * rstd * gg.z + bb.z;
+        o.w = v[i].w * rstd * gg.w + bb.w;
+        yr[lane + 64 * i] = o;
+    }
+}
+
+hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
+                            hipStream_t s) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (dim == 768)
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, b, y, rows, eps);
+    else if (dim == 512)
+        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, b, y, rows, eps);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// frames[b] = conv-chain output length of sum(mask[b,:])   (HF modeling:569-598; HF uses cumsum(-1)[-1] = the sum)
+__global__ __launch_bounds__(256) void frame_counts_kernel(const int32_t* __restrict__ mask, long L,
+                                                           int32_t* __restrict__ frames) {
+    __shared__ long part[4];
+    const int b = blockIdx.x;
+    long n = 0;
+    if (mask) {
+        const int32_t* m = mask + (long)b * L;
+        for (long i = threadIdx.x; i < L; i += 256) n += m[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+        __syncthreads();
+        n = part[0] + part[1] + part[2] + part[3];
+    } else {
+        n = L;
+    }
+    if (threadIdx.x == 0) {
+        const int ks[7] = {10, 3, 3, 3, 3, 2, 2}, ss[7] = {5, 2, 2, 2, 2, 2, 2};
+        for (int i = 0; i < 7; ++i) {
+            // torch.div(n - k, s, rounding_mode="floor") + 1: floor division also for negative n - k
+            long d = n - ks[i];
+            long qd = d >= 0 ? d / ss[i] : -((-d + ss[i] - 1) / ss[i]);
+            n = qd + 1;
+        }
+        frames[b] = (int32_t)n;
+    }
+}
+
+hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s) {
+    hipLaunchKernelGGL(frame_counts_kernel, dim3(B), dim3(256), 0, s, mask, L, frames);
+    return hipGetLastError();
+}
+
+// Conv1d weight [N, C, k] -> tap-major [N, k*C] so that a channels-last input row run is the GEMM's A row.
+__global__ void relayout_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int C, int k) {
+    const long total = (long)N * C * k;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int tap = (int)((i / C) % k);
+        const int n = (int)(i / ((long)C * k));
+        out[i] = w[((long)n * C + c) * k + tap];
+    }
+}
+
+hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C, int k, hipStream_t s) {
+    hipLaunchKernelGGL(relayout_conv_weight_kernel, dim3(1024), dim3(256), 0, s, w, out, N, C, k);
+    return hipGetLastError();
+}
+
+// weight_norm(dim=2) of the positional conv (HF modeling:358-379): w[o,i,tap] = g[tap] * v[o,i,tap] / ||v[:,:,tap]||,
+// the norm over all 768*48 (o,i) pairs of one tap; written as [group][tap][o_local][i].
+__global__ __launch_bounds__(256) void fold_pos_conv_kernel(const float* __restrict__ g, const float* __restrict__ v,
+                                                            float* __restrict__ out) {
+    __shared__ double part[4];
+    const int tap = blockIdx.x;
+    double ss = 0.0;
+    for (int e = threadIdx.x; e < kHidden * kPosCg; e += 256) {
+        const double x = v[(long)e * kPosK + tap];
+        ss += x * x;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float norm = (float)sqrt(part[0] + part[1] + part[2] + part[3]);
+    const float scale = g[tap] / norm;
+    for (int e = threadIdx.x; e < kHidden * kPosCg; e += 256) {
+        const int i = e % kPosCg, o = e / kPosCg;
+        const int grp = o / kPosCg, ol = o % kPosCg;
+        out[(((long)grp * kPosK + tap) * kPosCg + ol) * kPosCg + i] = v[(long)e * kPosK + tap] * scale;
+    }
+}
+
+hipError_t launch_fold_pos_conv(const float* g, const float* v, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(fold_pos_conv_kernel, dim3(kPosK), dim3(256), 0, s, g, v, out);
+    return hipGetLastError();
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i] * scale;
+}
+
+hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(512), dim3(256), 0, s, src, dst, n, scale);
+    return hipGetLastError();
+}
+
+// Sinusoidal position table (HF modeling:305-321): row p = [sin(p*w_k) | cos(p*w_k)], w_k = exp(-k*ln(1e4)/383),
+// every step rounded to fp32 like the torch expression it restates; row 1 (the padding row) is zero.
+__global__ void sinusoid_table_kernel(float* __restrict__ tab, int rows) {
+    const long total = (long)rows * (kHidden / 2);
+    const float c = (float)(-9.210340371976184 / (double)(kHidden / 2 - 1));  // -ln(1e4)/383 rounded once from double, as torch does
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (kHidden / 2));
+        const int p = (int)(i / (kHidden / 2));
+        const float w = expf(__fmul_rn((float)k, c));
+        const float ang = __fmul_rn((float)p, w);
+        float sv = sinf(ang), cv = cosf(ang);
+        if (p == 1) sv = cv = 0.f;
+        tab[(long)p * kHidden + k] = sv;
+        tab[(long)p * kHidden + kHidden / 2 + k] = cv;
+    }
+}
+
+hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(sinusoid_table_kernel, dim3(1024), dim3(256), 0, s, tab, rows);
+    return hipGetLastError();
+}
+
+}  // namespace loco

@@ -1,0 +1,343 @@
+"""Host-side mirror of the HuggingFace module contract the reference scripts use.
+
+    model.speecht5.encoder.wrapped_encoder.load_state_dict(encoder_state_dict)     (…base…py:99)
+    model.speecht5.encoder.prenet.load_state_dict(speech_prenet_state_dict)        (…base…py:100)
+    model.eval(); with torch.no_grad(): out = model.speecht5.encoder(**audios)     (…base…py:102-108)
+    embeddings = out.last_hidden_state.cpu().detach().numpy()                      (…base…py:109)
+
+(`…base…py` = /root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py; the fine-tuned
+script makes the same call at :104-106.)  `SpeechT5EncoderWithSpeechPrenetMI355X` keeps exactly that
+surface -- the same sub-module names, the same state-dict keys (HF 5.x spelling and the 4.30.2
+``weight_g/weight_v`` spelling the reference's pickles use), keyword ``forward(input_values,
+attention_mask=None, output_attentions=None, output_hidden_states=None, return_dict=None)`` returning an
+object with ``.last_hidden_state`` (HF modeling_speecht5.py:1339-1358) -- but every FLOP runs in the
+hand-written gfx950 kernels behind the C ABI of ``include/loco_asr.h``.  PyTorch is used for what it
+is good at here: owning device memory, streams and (in ``dp.py``) the RCCL process group.
+
+There is no fallback: on a machine without the built HIP library or without a ROCm device the
+constructor/forward raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+from .synth import (CONV_DIM, CONV_KERNEL, FFN, HEAD_DIM, HEADS, HIDDEN, LAYERS, POS_CONV_GROUPS, POS_CONV_K, REL_MAX)
+
+PAD_TOKEN_ID = 1
+MAX_SPEECH_POSITIONS = 4000
+
+
+@dataclass
+class BaseModelOutput:
+    """Field-compatible stand-in for transformers.modeling_outputs.BaseModelOutput."""
+    last_hidden_state: torch.Tensor = None
+    hidden_states: Optional[Tuple[torch.Tensor, ...]] = None
+    attentions: Optional[Tuple[torch.Tensor, ...]] = None
+
+    def to_tuple(self):
+        return tuple(v for v in (self.last_hidden_state, self.hidden_states, self.attentions) if v is not None)
+
+    def __getitem__(self, i):
+        return self.to_tuple()[i] if isinstance(i, int) else getattr(self, i)
+
+    def __iter__(self):
+        return iter(self.to_tuple())
+
+
+def _register(root: nn.Module, dotted: str, shape, init: float = 0.0):
+    """Create nested containers so that root.state_dict() yields the HF key `dotted`."""
+    parts = dotted.split(".")
+    mod = root
+    for name in parts[:-1]:
+        if not hasattr(mod, name):
+            mod.add_module(name, nn.Module())
+        mod = getattr(mod, name)
+    p = nn.Parameter(torch.full(tuple(shape), float(init)), requires_grad=False)
+    mod.register_parameter(parts[-1], p)
+
+
+def sinusoid_table(rows: int, dim: int = HIDDEN) -> torch.Tensor:
+    """HF SpeechT5SinusoidalPositionalEmbedding.get_embedding (modeling_speecht5.py:305-321), same torch
+    expression so that the table is bit-identical to the one HF builds at module init (weights, not hot path)."""
+    half = dim // 2
+    w = torch.exp(torch.arange(half, dtype=torch.int64).float() * -(math.log(10000) / (half - 1)))
+    ang = torch.arange(rows, dtype=torch.int64).float().unsqueeze(1) * w.unsqueeze(0)
+    tab = torch.cat([torch.sin(ang), torch.cos(ang)], dim=1).view(rows, -1)
+    tab[PAD_TOKEN_ID, :] = 0
+    return tab
+
+
+class _WeightHolder(nn.Module):
+    """A sub-module (prenet / wrapped_encoder) that only owns HF-named parameters."""
+
+    def __init__(self, owner_ref):
+        super().__init__()
+        self._owner_ref = owner_ref
+
+    def _mark_dirty(self):
+        owner = self._owner_ref()
+        if owner is not None:
+            owner._weights_dirty = True
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        sd = self._translate(dict(state_dict))
+        res = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._mark_dirty()
+        return res
+
+    def _translate(self, sd):
+        return sd
+
+    def _apply(self, fn, recurse=True):
+        self._mark_dirty()
+        return super()._apply(fn, recurse)
+
+
+class SpeechT5SpeechEncoderPrenetMI355X(_WeightHolder):
+    """Parameter names of HF SpeechT5SpeechEncoderPrenet (modeling_speecht5.py:513-532)."""
+
+    def __init__(self, owner_ref):
+        super().__init__(owner_ref)
+        _register(self, "masked_spec_embed", (HIDDEN,))
+        for i, k in enumerate(CONV_KERNEL):
+            _register(self, f"feature_encoder.conv_layers.{i}.conv.weight", (CONV_DIM, 1 if i == 0 else CONV_DIM, k))
+        _register(self, "feature_encoder.conv_layers.0.layer_norm.weight", (CONV_DIM,), 1.0)
+        _register(self, "feature_encoder.conv_layers.0.layer_norm.bias", (CONV_DIM,))
+        _register(self, "feature_projection.layer_norm.weight", (CONV_DIM,), 1.0)
+        _register(self, "feature_projection.layer_norm.bias", (CONV_DIM,))
+        _register(self, "feature_projection.projection.weight", (HIDDEN, CONV_DIM))
+        _register(self, "feature_projection.projection.bias", (HIDDEN,))
+        _register(self, "pos_conv_embed.conv.bias", (HIDDEN,))
+        _register(self, "pos_conv_embed.conv.parametrizations.weight.original0", (1, 1, POS_CONV_K), 1.0)
+        _register(self, "pos_conv_embed.conv.parametrizations.weight.original1", (HIDDEN, HIDDEN // POS_CONV_GROUPS, POS_CONV_K))
+
+    def _translate(self, sd):
+        # transformers 4.30.2 (the reference's pin) spells the weight-norm pair weight_g / weight_v, and the
+        # reference's pickled prenet dict also carries the sinusoid buffer (map_speecht5_hf.py:164-166).
+        for old, new in (("pos_conv_embed.conv.weight_g", "pos_conv_embed.conv.parametrizations.weight.original0"),
+                         ("pos_conv_embed.conv.weight_v", "pos_conv_embed.conv.parametrizations.weight.original1")):
+            if old in sd:
+                sd[new] = sd.pop(old)
+        sd.pop("pos_sinusoidal_embed.weights", None)
+        return sd
+
+
+class SpeechT5EncoderMI355X(_WeightHolder):
+    """Parameter names of HF SpeechT5Encoder (modeling_speecht5.py:1212-1232)."""
+
+    def __init__(self, owner_ref, layers: int):
+        super().__init__(owner_ref)
+        _register(self, "layer_norm.weight", (HIDDEN,), 1.0)
+        _register(self, "layer_norm.bias", (HIDDEN,))
+        _register(self, "embed_positions.pe_k.weight", (2 * REL_MAX, HEAD_DIM))
+        for l in range(layers):
+            b = f"layers.{l}."
+            for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                _register(self, f"{b}attention.{proj}.weight", (HIDDEN, HIDDEN))
+                _register(self, f"{b}attention.{proj}.bias", (HIDDEN,))
+            for ln in ("layer_norm", "final_layer_norm"):
+                _register(self, f"{b}{ln}.weight", (HIDDEN,), 1.0)
+                _register(self, f"{b}{ln}.bias", (HIDDEN,))
+            _register(self, f"{b}feed_forward.intermediate_dense.weight", (FFN, HIDDEN))
+            _register(self, f"{b}feed_forward.intermediate_dense.bias", (FFN,))
+            _register(self, f"{b}feed_forward.output_dense.weight", (HIDDEN, FFN))
+            _register(self, f"{b}feed_forward.output_dense.bias", (HIDDEN,))
+
+
+class _Ref:
+    """weak-ish back reference that nn.Module does not register as a child."""
+
+    def __init__(self):
+        self.obj = None
+
+    def __call__(self):
+        return self.obj
+
+
+class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
+    """Drop-in for ``SpeechT5ForSpeechToText(...).speecht5.encoder`` (HF modeling_speecht5.py:1325-1358)."""
+
+    def __init__(self, layers: int = LAYERS):
+        super().__init__()
+        self._lib = _lib.load()  # raises when the HIP library is missing: no fallback
+        ref = _Ref()
+        self.prenet = SpeechT5SpeechEncoderPrenetMI355X(ref)
+        self.wrapped_encoder = SpeechT5EncoderMI355X(ref, layers)
+        ref.obj = self
+        self.num_layers = layers
+        self._handle = None
+        self._handle_device = None
+        self._weights_dirty = True
+        self._workspace = None
+        self._sin_rows = 0
+        self._taps = None
+        self.eval()
+
+    # -- lifetime ----------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None):
+                self._lib.loco_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _device(self) -> torch.device:
+        return next(self.prenet.parameters()).device
+
+    def _ensure_handle(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError(
+                "SpeechT5EncoderWithSpeechPrenetMI355X runs only on an AMD GPU through its HIP kernels "
+                f"(got device {device}); move the module and its inputs with .to('cuda'). There is no CPU path.")
+        if self._handle is not None and self._handle_device != device:
+            self._lib.loco_destroy(self._handle)
+            self._handle = None
+        if self._handle is None:
+            cfg = _lib.LocoConfig()
+            self._lib.loco_default_config(C.byref(cfg))
+            cfg.layers = self.num_layers
+            with torch.cuda.device(device):
+                h = self._lib.loco_create(C.byref(cfg))
+            if not h:
+                raise _lib.LocoError("loco_create: " + self._lib.loco_last_error().decode())
+            self._handle = C.c_void_p(h)
+            self._handle_device = device
+            self._weights_dirty = True
+            self._sin_rows = 0
+
+    def _sync_weights(self, device: torch.device, min_sin_rows: int):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        if self._weights_dirty:
+            for prefix, mod in (("prenet.", self.prenet), ("wrapped_encoder.", self.wrapped_encoder)):
+                for name, p in mod.state_dict().items():
+                    t = p.detach()
+                    if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                        t = t.to(device=device, dtype=torch.float32).contiguous()
+                    shape = (C.c_int64 * t.dim())(*t.shape)
+                    _lib.check(self._lib.loco_set_weight(self._handle, (prefix + name).encode(), C.c_void_p(t.data_ptr()),
+                                                         shape, t.dim()), "load_state_dict")
+            self._sin_rows = 0
+        if self._sin_rows < min_sin_rows:
+            rows = max(MAX_SPEECH_POSITIONS + PAD_TOKEN_ID + 1 + 2, min_sin_rows + 2)
+            tab = sinusoid_table(rows).contiguous()
+            shape = (C.c_int64 * 2)(rows, HIDDEN)
+            _lib.check(self._lib.loco_set_weight(self._handle, b"prenet.pos_sinusoidal_embed.weights",
+                                                 C.c_void_p(tab.data_ptr()), shape, 2), "sinusoid table")
+            self._sin_rows = rows
+        if self._weights_dirty:
+            _lib.check(self._lib.loco_finalize_weights(self._handle, stream), "finalize_weights")
+            self._weights_dirty = False
+
+    # -- tools for tests / bench -------------------------------------------------------------------------
+    def set_profiling(self, on: bool):
+        self._ensure_handle(self._device())
+        _lib.check(self._lib.loco_set_profiling(self._handle, int(on)))
+
+    def profile_reset(self):
+        _lib.check(self._lib.loco_profile_reset(self._handle))
+
+    def profile_read(self):
+        arr = (_lib.KernelStat * 16)()
+        n = _lib.check(self._lib.loco_profile_read(self._handle, arr, 16))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
+                     bytes=arr[i].bytes) for i in range(n)]
+
+    def workspace_bytes(self, batch: int, samples: int) -> int:
+        self._ensure_handle(self._device())
+        return int(self._lib.loco_workspace_bytes(self._handle, batch, samples))
+
+    # -- forward -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
+                return_dict: Optional[bool] = None, stage_taps: Optional[dict] = None, **kwargs):
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only (the reference calls it under "
+                               "model.eval() + torch.no_grad()); call .eval()")
+        if output_attentions:
+            raise NotImplementedError("output_attentions=True: the flash-style attention kernel never forms the [T,T] weights")
+        if input_values.dim() != 2:
+            raise ValueError(f"input_values must be [batch, samples], got {tuple(input_values.shape)}")
+        device = input_values.device
+        self._ensure_handle(device)
+        if self._device() != device:
+            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
+        x = input_values
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        B, L = x.shape
+        T = int(self._lib.loco_output_frames(L))
+        if T < 1:
+            raise ValueError(f"input of {L} samples is shorter than one encoder frame (400 samples)")
+        m = None
+        if attention_mask is not None:
+            if attention_mask.shape != x.shape:
+                raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(x.shape)}")
+            m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(device):
+            self._sync_weights(device, T + 2)
+            need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+            out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+            frames = torch.empty((B,), dtype=torch.int32, device=device)
+            hs, hs_ptrs = None, None
+            if output_hidden_states:
+                hs = [torch.empty_like(out) for _ in range(self.num_layers + 1)]
+                hs_ptrs = (C.c_void_p * (self.num_layers + 1))(*[t.data_ptr() for t in hs])
+            taps = None
+            if stage_taps is not None:
+                taps = dict(conv_stack=torch.empty((B, T, CONV_DIM), dtype=torch.float32, device=device),
+                            feature_projection=torch.empty_like(out), prenet=torch.empty_like(out))
+                _lib.check(self._lib.loco_set_taps(self._handle, taps["conv_stack"].data_ptr(),
+                                                   taps["feature_projection"].data_ptr(), taps["prenet"].data_ptr()))
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            try:
+                _lib.check(self._lib.loco_forward(self._handle, C.c_void_p(x.data_ptr()),
+                                                  C.c_void_p(m.data_ptr()) if m is not None else None, B, L,
+                                                  C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
+                                                  C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream),
+                           "loco_forward")
+            finally:
+                if taps is not None:
+                    _lib.check(self._lib.loco_set_taps(self._handle, None, None, None))
+        if stage_taps is not None:
+            stage_taps.update(taps)
+            stage_taps["frames"] = frames
+        self.last_frames = frames
+        hidden = tuple(hs) if hs is not None else None
+        if return_dict is False:
+            return tuple(v for v in (out, hidden) if v is not None)
+        return BaseModelOutput(last_hidden_state=out, hidden_states=hidden, attentions=None)
+
+
+class _SpeechT5Core(nn.Module):
+    def __init__(self, encoder):
+        super().__init__()
+        self.encoder = encoder
+
+
+class SpeechT5ForSpeechToTextMI355X(nn.Module):
+    """Only as much of HF's SpeechT5ForSpeechToText as the reference touches: ``.speecht5.encoder``."""
+
+    def __init__(self, layers: int = LAYERS):
+        super().__init__()
+        self.speecht5 = _SpeechT5Core(SpeechT5EncoderWithSpeechPrenetMI355X(layers))
+        self.eval()
+
+    @classmethod
+    def from_state_dicts(cls, prenet_state_dict, encoder_state_dict, layers: int = LAYERS):
+        """What the base script does after from_pretrained (…base…py:98-100), minus the hub download."""
+        model = cls(layers)
+        model.speecht5.encoder.wrapped_encoder.load_state_dict(encoder_state_dict)
+        model.speecht5.encoder.prenet.load_state_dict(prenet_state_dict)
+        return model

@@ -1,0 +1,79 @@
+"""Host-side waveform batching with the contract of HF's SpeechT5FeatureExtractor for raw audio.
+
+The reference's collate_fn calls ``processor(audio=audios, sampling_rate=16000, return_tensors="pt",
+padding="longest").to(device)`` (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:60),
+which dispatches to ``SpeechT5FeatureExtractor._process_audio``
+(transformers/models/speecht5/feature_extraction_speecht5.py:275-360): zero-pad every clip on the right to
+the longest one, return ``input_values`` f32 [B, L] and ``attention_mask`` i32 [B, L]; when
+``do_normalize`` is set, each clip is first shifted/scaled to zero mean and unit variance over its
+UNPADDED samples with epsilon 1e-7 (feature_extraction_speecht5.py:119-138).  The class default is
+``do_normalize=False`` (:77); the hub checkpoint's value cannot be checked offline, so both are supported.
+
+This stays Python/numpy on the host exactly as in the reference; it hands over pinned host tensors so the
+H2D copy in ``.to(device)`` can overlap compute.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+class BatchFeature(dict):
+    """dict with ``.to(device)`` and attribute access, so ``encoder(**audios)`` works as in the reference."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def to(self, device, non_blocking: bool = True):
+        return BatchFeature({k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in self.items()})
+
+
+class SpeechT5FeatureExtractorMI355X:
+    model_input_names = ["input_values", "attention_mask"]
+
+    def __init__(self, sampling_rate: int = 16000, padding_value: float = 0.0, do_normalize: bool = False,
+                 return_attention_mask: bool = True, pin_memory: bool = False):
+        self.sampling_rate = sampling_rate
+        self.padding_value = padding_value
+        self.do_normalize = do_normalize
+        self.return_attention_mask = return_attention_mask
+        self.pin_memory = pin_memory
+
+    @staticmethod
+    def zero_mean_unit_var_norm(x: np.ndarray) -> np.ndarray:
+        return ((x - x.mean()) / np.sqrt(x.var() + 1e-7)).astype(np.float32)
+
+    def __call__(self, audio=None, sampling_rate=None, return_tensors="pt", padding="longest", **_):
+        if audio is None:
+            raise ValueError("You must provide `audio`.")  # same message class as HF's ValueError
+        if sampling_rate is not None and sampling_rate != self.sampling_rate:
+            raise ValueError(f"The model was trained at {self.sampling_rate} Hz; got sampling_rate={sampling_rate}.")
+        if isinstance(audio, np.ndarray) and audio.ndim == 1 or torch.is_tensor(audio) and audio.dim() == 1:
+            audio = [audio]
+        clips = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audio]
+        if not clips:
+            raise ValueError("empty batch")
+        if self.do_normalize:
+            clips = [self.zero_mean_unit_var_norm(c) for c in clips]
+        lmax = max(len(c) for c in clips) if padding in ("longest", True) else None
+        if lmax is None:
+            if len({len(c) for c in clips}) != 1:
+                raise ValueError("clips differ in length; use padding='longest'")
+            lmax = len(clips[0])
+        B = len(clips)
+        x = torch.full((B, lmax), float(self.padding_value), dtype=torch.float32)
+        m = torch.zeros((B, lmax), dtype=torch.int32)
+        for i, c in enumerate(clips):
+            x[i, :len(c)] = torch.from_numpy(c)
+            m[i, :len(c)] = 1
+        if self.pin_memory and torch.cuda.is_available():
+            x, m = x.pin_memory(), m.pin_memory()
+        out = BatchFeature(input_values=x)
+        if self.return_attention_mask:
+            out["attention_mask"] = m
+        if return_tensors == "np":
+            out = BatchFeature({k: v.numpy() for k, v in out.items()})
+        return out

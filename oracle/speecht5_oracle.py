@@ -147,18 +147,11 @@ def speech_prenet(x, attention_mask, sd, prefix="prenet.", dtype=torch.float32, 
     return h, frames
 
 
-def attention(x, frames, sd, lp, pe_k, dtype=torch.float32, q_block=512):
-    """HF:872-986 with the compact relative-position bias and query blocking.
-    x [B,T,768]; frames LongTensor[B] or None (keys >= frames[b] are masked for every query)."""
-    B, T, D = x.shape
-    H = HEADS
-    dh = D // H
-    q = F.linear(x, _t(sd, lp + "attention.q_proj.weight", dtype), _t(sd, lp + "attention.q_proj.bias", dtype)) * dh ** -0.5
-    k = F.linear(x, _t(sd, lp + "attention.k_proj.weight", dtype), _t(sd, lp + "attention.k_proj.bias", dtype))
-    v = F.linear(x, _t(sd, lp + "attention.v_proj.weight", dtype), _t(sd, lp + "attention.v_proj.bias", dtype))
-    q = q.view(B, T, H, dh).transpose(1, 2)  # [B,H,T,dh]
-    k = k.view(B, T, H, dh).transpose(1, 2)
-    v = v.view(B, T, H, dh).transpose(1, 2)
+def attention_core(q, k, v, pe_k, frames, q_block=512):
+    """softmax(q k^T + rel-pos bias + key mask) v for q (already scaled), k, v of shape [B,H,T,dh]
+    (HF:930-969), in query blocks, with bias[i,j] = (q_i . pe_k^T)[clip(i-j,-160,159)+160]."""
+    B, H, T, dh = q.shape
+    dtype = q.dtype
     out = torch.empty(B, H, T, dh, dtype=dtype)
     jj = torch.arange(T)
     neg = torch.finfo(dtype).min
@@ -174,6 +167,22 @@ def attention(x, frames, sd, lp, pe_k, dtype=torch.float32, q_block=512):
             s = s + masked[:, None, None, :].to(dtype) * neg  # additive finfo.min (HF:947-953)
         p = torch.softmax(s, dim=-1)
         out[:, :, i0:i1] = p @ v
+    return out
+
+
+def attention(x, frames, sd, lp, pe_k, dtype=torch.float32, q_block=512):
+    """HF:872-986 with the compact relative-position bias and query blocking.
+    x [B,T,768]; frames LongTensor[B] or None (keys >= frames[b] are masked for every query)."""
+    B, T, D = x.shape
+    H = HEADS
+    dh = D // H
+    q = F.linear(x, _t(sd, lp + "attention.q_proj.weight", dtype), _t(sd, lp + "attention.q_proj.bias", dtype)) * dh ** -0.5
+    k = F.linear(x, _t(sd, lp + "attention.k_proj.weight", dtype), _t(sd, lp + "attention.k_proj.bias", dtype))
+    v = F.linear(x, _t(sd, lp + "attention.v_proj.weight", dtype), _t(sd, lp + "attention.v_proj.bias", dtype))
+    q = q.view(B, T, H, dh).transpose(1, 2)  # [B,H,T,dh]
+    k = k.view(B, T, H, dh).transpose(1, 2)
+    v = v.view(B, T, H, dh).transpose(1, 2)
+    out = attention_core(q, k, v, pe_k, frames, q_block)
     o = out.transpose(1, 2).reshape(B, T, D)
     return F.linear(o, _t(sd, lp + "attention.out_proj.weight", dtype), _t(sd, lp + "attention.out_proj.bias", dtype))
 

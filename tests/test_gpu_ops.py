@@ -1,0 +1,218 @@
+"""Per-kernel parity on one MI355X: every HIP kernel, called through the C ABI (include/loco_asr.h), against
+the same op of the CPU oracle / plain torch fp32 on identical seeded inputs.
+
+Tolerances (relative L2, fp32 vs fp32): 2e-6 for byte movers and reductions, 1e-5 for the MFMA
+contractions (exact-fp32 products, different summation order than the CPU's), far inside the 1e-3 the
+embedding must meet end to end.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import check, dev, la, lib, ptr, rel_l2, stream
+
+
+def hu(key, shape, scale=1.0):
+    return torch.from_numpy(la.synth.hashed_uniform(key, shape, 11)) * scale
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 768), (5, 512), (1499 * 2, 768), (4097, 512)])
+def test_layernorm(rows, dim):
+    x = hu("ln.x", (rows, dim), 3.0) + 0.5
+    g = hu("ln.g", (dim,)) + 1.0
+    b = hu("ln.b", (dim,))
+    xd, y = dev(x), torch.empty(rows, dim, device="cuda")
+    check(lib().loco_op_layernorm(ptr(xd), ptr(dev(g)), ptr(dev(b)), ptr(y), rows, dim, 1e-5, stream()))
+    ref = F.layer_norm(x, (dim,), g, b, 1e-5)
+    assert rel_l2(y, ref) < 2e-6
+    # in place
+    check(lib().loco_op_layernorm(ptr(xd), ptr(dev(g)), ptr(dev(b)), ptr(xd), rows, dim, 1e-5, stream()))
+    assert torch.equal(xd, y)
+
+
+def test_layernorm_rejects_other_widths():
+    x = torch.zeros(4, 640, device="cuda")
+    with pytest.raises(ValueError):
+        check(lib().loco_op_layernorm(ptr(x), ptr(x), ptr(x), ptr(x), 4, 640, 1e-5, stream()))
+
+
+def gemm(A, W, bias=None, R=None, epi=0, lda=None, M=None, nb1=1, nb2=1, sA=(0, 0), sC=(0, 0), out=None, ldc=None):
+    N, K = W.shape
+    lda = lda if lda is not None else A.shape[-1]
+    M = M if M is not None else A.shape[0]
+    ldc = ldc or N
+    C_ = out if out is not None else torch.empty(nb1 * nb2 * M, N, device="cuda")
+    check(lib().loco_op_gemm(ptr(A), lda, ptr(W), W.shape[1], ptr(bias), ptr(R), ldc, ptr(C_), ldc, M, N, K, epi, nb1, nb2,
+                             sA[0], sA[1], sC[0], sC[1], stream()), "gemm")
+    return C_
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1, 768, 768), (300, 320, 64), (1499, 2304, 768), (257, 768, 3072),
+                                    (130, 512, 1536)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_linear(M, N, K, epi):
+    A = hu("g.a", (M, K))
+    W = hu("g.w", (N, K), 2.0 / math.sqrt(K))
+    b = hu("g.b", (N,))
+    R = hu("g.r", (M, N))
+    out = gemm(dev(A), dev(W), dev(b), dev(R) if epi == 2 else None, epi)
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+    if epi == 2:
+        ref = ref + R.double()
+    assert rel_l2(out, ref) < 1e-6  # vs fp64: fp32 MFMA is an exact-product fmaf chain
+
+
+def test_gemm_identity_asymmetric():
+    # A = I with an asymmetric W catches a transposed C write (guide §3)
+    K = 128
+    A = torch.eye(K)
+    W = hu("g.asym", (96, K))
+    out = gemm(dev(A), dev(W))
+    assert torch.equal(out.cpu(), W.t().contiguous())
+
+
+@pytest.mark.parametrize("k,s,Tin,B", [(3, 2, 401, 2), (2, 2, 37, 3), (3, 2, 4799, 1)])
+def test_gemm_as_strided_conv(k, s, Tin, B):
+    """Conv1d layers 1-6 (HF modeling:216-228): channels-last rows, lda = s*C, K = k*C, tap-major weight."""
+    Cc = 512
+    x = hu("c.x", (B, Tin, Cc))
+    w = hu("c.w", (Cc, Cc, k), math.sqrt(2.0 / (Cc * k)))
+    Tout = (Tin - k) // s + 1
+    wt = w.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    out = gemm(dev(x), dev(wt), epi=1, lda=s * Cc, M=Tout, nb1=B, sA=(Tin * Cc, 0), sC=(Tout * Cc, 0))
+    ref = F.conv1d(x.transpose(1, 2).double(), w.double(), stride=s)
+    ref = (0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))).transpose(1, 2).reshape(B * Tout, Cc)
+    assert rel_l2(out, ref) < 1e-6
+
+
+def test_gemm_rejects_bad_k():
+    a = torch.zeros(4, 48, device="cuda")
+    with pytest.raises(ValueError):
+        gemm(a, torch.zeros(8, 48, device="cuda"))
+
+
+@pytest.mark.parametrize("lengths", [[400], [16000, 9000], [80000, 48000, 801]])
+def test_conv0_groupnorm_gelu(lengths, oracle):
+    x, m = la.synth.batch(lengths)
+    B, L = x.shape
+    sd = la.synth.encoder_state_dict(0, layers=0)
+    p = "prenet.feature_encoder.conv_layers.0."
+    w, gw, gb = sd[p + "conv.weight"], sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]
+    T0 = (L - 10) // 5 + 1
+    out = torch.empty(B, T0, 512, device="cuda")
+    scratch = torch.empty(lib().loco_conv0_scratch_bytes(B), dtype=torch.uint8, device="cuda")
+    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), B, L, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out),
+                                      ptr(scratch), stream()))
+    h = F.conv1d(torch.from_numpy(x).double()[:, None], torch.from_numpy(w).double(), stride=5)
+    mean = h.mean(2, keepdim=True)
+    var = ((h - mean) ** 2).mean(2, keepdim=True)
+    h = (h - mean) / torch.sqrt(var + 1e-5) * torch.from_numpy(gw).double()[None, :, None] + torch.from_numpy(gb).double()[None, :, None]
+    ref = (0.5 * h * (1 + torch.erf(h / math.sqrt(2)))).transpose(1, 2)
+    assert rel_l2(out, ref) < 2e-6
+    # bitwise reproducible (fixed-order fp64 reduction)
+    out2 = torch.empty_like(out)
+    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), B, L, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out2),
+                                      ptr(scratch), stream()))
+    assert torch.equal(out, out2)
+
+
+def test_conv0_dc_offset_is_stable():
+    """GroupNorm statistics from waveform moments: a large DC offset must not lose the variance."""
+    x = (la.synth.clip(3, 8000) + 5.0)[None]
+    sd = la.synth.encoder_state_dict(0, layers=0)
+    p = "prenet.feature_encoder.conv_layers.0."
+    w, gw, gb = sd[p + "conv.weight"], sd[p + "layer_norm.weight"], sd[p + "layer_norm.bias"]
+    T0 = (8000 - 10) // 5 + 1
+    out = torch.empty(1, T0, 512, device="cuda")
+    scratch = torch.empty(lib().loco_conv0_scratch_bytes(1), dtype=torch.uint8, device="cuda")
+    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), 1, 8000, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out),
+                                      ptr(scratch), stream()))
+    h = F.conv1d(torch.from_numpy(x).double()[:, None], torch.from_numpy(w).double(), stride=5)
+    h = (h - h.mean(2, keepdim=True)) / torch.sqrt(h.var(2, unbiased=False, keepdim=True) + 1e-5)
+    h = h * torch.from_numpy(gw).double()[None, :, None] + torch.from_numpy(gb).double()[None, :, None]
+    ref = (0.5 * h * (1 + torch.erf(h / math.sqrt(2)))).transpose(1, 2)
+    assert rel_l2(out, ref) < 2e-5  # the fp32 conv output itself carries the offset; stats stay exact
+
+
+def test_frame_counts(oracle):
+    L = 100000
+    lens = [100000, 99999, 400, 399 + 320, 48000, 80000, 12345]
+    m = torch.zeros(len(lens), L, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        m[i, :n] = 1
+    fr = torch.empty(len(lens), dtype=torch.int32, device="cuda")
+    check(lib().loco_op_frame_counts(ptr(m.cuda()), len(lens), L, ptr(fr), stream()))
+    assert fr.cpu().tolist() == [oracle.feat_extract_output_lengths(n) for n in lens]
+    check(lib().loco_op_frame_counts(None, len(lens), L, ptr(fr), stream()))
+    assert fr.cpu().tolist() == [oracle.feat_extract_output_lengths(L)] * len(lens)
+    assert lib().loco_output_frames(480000) == 1499 and lib().loco_output_frames(9600000) == 29999
+
+
+def fold_pos_conv(sd, oracle):
+    w = oracle.pos_conv_weight(sd)  # [768,48,128]
+    return w.view(16, 48, 48, 128).permute(0, 3, 1, 2).contiguous()  # [g][tap][o][i]
+
+
+@pytest.mark.parametrize("B,T,frames", [(1, 1, None), (2, 49, [49, 30]), (1, 300, None), (3, 129, [129, 1, 77])])
+def test_pos_conv_and_sinusoid(B, T, frames, oracle):
+    sd = la.synth.encoder_state_dict(0, layers=0)
+    h = hu("pc.h", (B, T, 768), 1.5)
+    wf = fold_pos_conv(sd, oracle)
+    bias = torch.from_numpy(sd["prenet.pos_conv_embed.conv.bias"])
+    tab = la.sinusoid_table(T + 2)
+    fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
+    out = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_pos_conv(ptr(dev(h)), ptr(dev(wf)), ptr(dev(bias)), ptr(dev(tab)),
+                                 ptr(fr.cuda()) if fr is not None else None, ptr(out), B, T, stream()))
+    w = oracle.pos_conv_weight(sd).double()
+    pc = F.conv1d(h.double().transpose(1, 2), w, bias.double(), padding=64, groups=16)[:, :, :-1]
+    ref = h.double() + (0.5 * pc * (1 + torch.erf(pc / math.sqrt(2)))).transpose(1, 2)
+    valid = torch.ones(B, T, dtype=torch.long) if fr is None else (torch.arange(T)[None] < fr[:, None].long()).long()
+    pos = torch.cumsum(valid, 1) * valid + 1
+    ref = ref + tab.double()[pos]
+    assert rel_l2(out, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,T,frames", [(1, 1, None), (2, 200, [200, 131]), (1, 333, None), (2, 450, [450, 65]), (1, 700, [64])])
+def test_attention_core(B, T, frames, oracle):
+    """flash attention incl. the compact relative-position bias across |i-j| = 159/160/161 and key masks."""
+    qkv = hu("at.qkv", (B, T, 2304), 1.5)
+    qkv[..., :768] *= 0.125 * 1.5  # q arrives pre-scaled
+    pe_k = hu("at.pe", (320, 64), 0.9)
+    q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
+    k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
+    v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
+    qp = (q @ pe_k.t()).contiguous()  # [B,12,T,320]
+    fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
+    ctx = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_attention(ptr(dev(qkv)), ptr(dev(qp)), ptr(fr.cuda()) if fr is not None else None, ptr(ctx), B, T, stream()))
+    ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None if fr is None else fr.long(), q_block=128)
+    ref = ref.transpose(1, 2).reshape(B, T, 768)
+    assert rel_l2(ctx, ref) < 3e-6
+
+
+def test_attention_forces_online_softmax_rescale(oracle):
+    """A key far down the sequence that dominates every row forces the running max to jump at a late tile
+    (guide rule 26: the rescale branch needs an input that takes it)."""
+    B, T = 1, 400
+    qkv = hu("at2.qkv", (B, T, 2304), 1.0)
+    qkv[..., :768] *= 0.125
+    qkv[0, 300, 768:1536] = qkv[0, :, :768].mean(0) * 0 + 6.0  # key 300: large positive dot with most queries
+    qkv[0, :, :768] = qkv[0, :, :768].abs()
+    pe_k = hu("at2.pe", (320, 64), 0.3)
+    q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
+    k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
+    v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
+    qp = (q @ pe_k.t()).contiguous()
+    ctx = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_attention(ptr(dev(qkv)), ptr(dev(qp)), None, ptr(ctx), B, T, stream()))
+    ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None).transpose(1, 2).reshape(B, T, 768)
+    assert rel_l2(ctx, ref) < 3e-6
