@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio frames/s through the SpeechT5-base speech encoder, 30 s x batch 32 per GPU
+(BASELINE.json configs[1]), synthetic 16 kHz audio resident in HBM, random-init weights of the named
+architecture (no checkpoint is reachable offline).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one forward of the whole hot path (conv feature extractor -> 12-layer encoder) over this rank's
+batch, plus -- for N > 1 -- the single RCCL all-gather of the [32, 1499, 768] embeddings that the
+data-parallel design performs per step.  Weak scaling: every rank encodes its own 32
+clips.  Rank 0 prints ONE JSON line; `value` = frames encoded by all ranks / max-over-ranks time.
+
+Extra objects on the line:
+  roofline      the dominant kernel (fp32-MFMA GEMM: 76 % of the FLOPs), algorithmic FLOPs / its summed launch
+                time, measured live with HIP events on the launch stream over the timed region; peak =
+                157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); traffic = PMC HBM bytes when
+                profiles/ holds them, else null.
+  cpu_baseline  the CPU oracle (oracle/speecht5_oracle.py, torch fp32, all host cores) timed on a bounded
+                sample of the same workload (30 s clips, batch 4) on rank 0 at N = 1 -- reported, not targeted.
+  embed_rel_l2  relative L2 of the GPU embeddings vs that oracle run on the sample clips (bar: 1e-3).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_SECONDS = 30
+BATCH_PER_GPU = 32
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: min(affinity, cgroup quota, cpu_count).  A 1-GPU slice of the
+    GPU box exposes all 256 hardware threads in cpu_count() but is entitled to a 16-CPU share; running the
+    CPU baseline with 256 torch threads there oversubscribes ~16x and measures scheduler thrash."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    cap = os.environ.get("LOCO_CPU_BASELINE_THREADS")
+    if cap:
+        n = max(1, int(cap))
+    elif n > 32:
+        n = 16  # documented CPU share of a one-GPU box when no quota is visible
+    return n
+
+
+def flops_per_clip(T: int) -> float:
+    """Algorithmic FLOPs of one clip: 284.2 MFLOP*T + 36 864 FLOP*T^2."""
+    return T * 284.2e6 + 36864.0 * T * T
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-clips", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the encoder has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    la = importlib.import_module("loco-asr_amd")
+    dp = importlib.import_module("loco-asr_amd.dp")
+    L = int(round(args.clip_seconds * 16000))
+    B = args.batch
+    T = la.synth.conv_out_length(L)
+
+    sd = la.synth.encoder_state_dict(0)
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                             {k: torch.from_numpy(v) for k, v in enc_sd.items()}).to(dev)
+    enc = model.speecht5.encoder
+    x_np, m_np = la.synth.batch([L] * B, first_index=rank * B)
+    x = torch.from_numpy(x_np).to(dev)
+    m = torch.from_numpy(m_np).to(dev)
+
+    def step():
+        out = enc(input_values=x, attention_mask=m).last_hidden_state
+        return dp.all_gather_embeddings(out) if world > 1 else out
+
+    for _ in range(args.warmup):
+        y = step()
+    torch.cuda.synchronize()
+    enc.set_profiling(True)
+    enc.profile_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    stats = enc.profile_read()
+    enc.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    frames_per_step = world * B * T
+    value = frames_per_step * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        by = {s["name"]: s for s in stats}
+        g = by.get("gemm_f32")
+        kernels = {s["name"]: {"launches_per_step": s["launches"] / args.steps, "ms_per_step": s["ms"] / args.steps,
+                               "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 and s["flops"] else None,
+                               "gbps": (s["bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 and s["bytes"] else None}
+                   for s in stats}
+        roofline = None
+        if g and g["ms"] > 0:
+            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+            roofline = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches_per_step": g["launches"] / args.steps,
+                        "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                        "flops_per_launch_avg": g["flops"] / g["launches"]}
+        whole = flops_per_clip(T) * B * world * args.steps / elapsed / 1e12
+        result = {
+            "metric": "audio frames/sec SpeechT5-base encoder, 30s×bs32 @1/2/4/8 GPU; embed L2 vs HF",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"SpeechT5-base speech encoder, synthetic 16 kHz {args.clip_seconds:g} s clips, batch {B} per GPU "
+                                   "(BASELINE.json configs[1]), random-init weights",
+                       "clip_seconds": args.clip_seconds, "batch_per_gpu": B, "global_batch": B * world, "frames_per_clip": T,
+                       "parallelism": f"dp{world}", "collective": "all_gather(embeddings)" if world > 1 else "none"},
+            "whole_path_tflops": round(whole, 2), "whole_path_frac_of_f32_mfma_peak": round(whole / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "roofline": roofline, "kernels": kernels,
+        }
+        # parity + CPU baseline on a bounded sample of the same workload (rank 0, N = 1 only)
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import speecht5_oracle as oracle  # the checker; never on the product path
+            nc = max(1, min(args.cpu_sample_clips, B))
+            threads = host_cores()
+            torch.set_num_threads(threads)
+            xs, ms = x_np[:nc], m_np[:nc]
+            oracle.encode(xs[:1, :16000 * 2], None, sd)  # warm-up (thread pool, weight conversion caches)
+            reps = []
+            ref = None
+            for _ in range(2):
+                t1 = time.perf_counter()
+                ref = oracle.encode(xs, ms, sd)
+                reps.append(time.perf_counter() - t1)
+            cpu_s = float(np.median(reps))
+            yg = enc(input_values=x[:nc], attention_mask=m[:nc]).last_hidden_state.cpu()
+            rel = float((yg.double() - ref.double()).norm() / ref.double().norm())
+            result["cpu_baseline"] = {"value": round(nc * T / cpu_s, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                      "kind": "port",
+                                      "sample": f"{nc} clips x {args.clip_seconds:g} s (batch {nc}) of the same synthetic workload, "
+                                                f"median of 2 runs, {cpu_s:.2f} s each, torch {torch.__version__} fp32"}
+            result["embed_rel_l2"] = rel
+            result["speedup_vs_cpu_baseline"] = round(value / (nc * T / cpu_s), 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -361,6 +361,7 @@ int loco_set_weight(loco_encoder* e, const char* key, const float* data, const i
     if (!t.d) HIP_TRY(hipMalloc(&t.d, (size_t)n * sizeof(float)));
     t.shape = shp;
     HIP_TRY(hipMemcpy(t.d, data, (size_t)n * sizeof(float), hipMemcpyDefault));
+    HIP_TRY(hipStreamSynchronize(nullptr));  // device-to-device copies may return early; the caller may free `data` now
     e->finalized = false;
     return LOCO_OK;
 }

@@ -27,12 +27,12 @@ def test_layernorm(rows, dim):
     x = hu("ln.x", (rows, dim), 3.0) + 0.5
     g = hu("ln.g", (dim,)) + 1.0
     b = hu("ln.b", (dim,))
-    xd, y = dev(x), torch.empty(rows, dim, device="cuda")
-    check(lib().loco_op_layernorm(ptr(xd), ptr(dev(g)), ptr(dev(b)), ptr(y), rows, dim, 1e-5, stream()))
+    xd, gd, bd, y = dev(x), dev(g), dev(b), torch.empty(rows, dim, device="cuda")
+    check(lib().loco_op_layernorm(ptr(xd), ptr(gd), ptr(bd), ptr(y), rows, dim, 1e-5, stream()))
     ref = F.layer_norm(x, (dim,), g, b, 1e-5)
     assert rel_l2(y, ref) < 2e-6
     # in place
-    check(lib().loco_op_layernorm(ptr(xd), ptr(dev(g)), ptr(dev(b)), ptr(xd), rows, dim, 1e-5, stream()))
+    check(lib().loco_op_layernorm(ptr(xd), ptr(gd), ptr(bd), ptr(xd), rows, dim, 1e-5, stream()))
     assert torch.equal(xd, y)
 
 
@@ -61,7 +61,8 @@ def test_gemm_linear(M, N, K, epi):
     W = hu("g.w", (N, K), 2.0 / math.sqrt(K))
     b = hu("g.b", (N,))
     R = hu("g.r", (M, N))
-    out = gemm(dev(A), dev(W), dev(b), dev(R) if epi == 2 else None, epi)
+    Ad, Wd, bd, Rd = dev(A), dev(W), dev(b), dev(R)
+    out = gemm(Ad, Wd, bd, Rd if epi == 2 else None, epi)
     ref = A.double() @ W.double().t() + b.double()
     if epi == 1:
         ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
@@ -75,7 +76,8 @@ def test_gemm_identity_asymmetric():
     K = 128
     A = torch.eye(K)
     W = hu("g.asym", (96, K))
-    out = gemm(dev(A), dev(W))
+    Ad, Wd = dev(A), dev(W)
+    out = gemm(Ad, Wd)
     assert torch.equal(out.cpu(), W.t().contiguous())
 
 
@@ -87,7 +89,8 @@ def test_gemm_as_strided_conv(k, s, Tin, B):
     w = hu("c.w", (Cc, Cc, k), math.sqrt(2.0 / (Cc * k)))
     Tout = (Tin - k) // s + 1
     wt = w.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
-    out = gemm(dev(x), dev(wt), epi=1, lda=s * Cc, M=Tout, nb1=B, sA=(Tin * Cc, 0), sC=(Tout * Cc, 0))
+    xd, wtd = dev(x), dev(wt)
+    out = gemm(xd, wtd, epi=1, lda=s * Cc, M=Tout, nb1=B, sA=(Tin * Cc, 0), sC=(Tout * Cc, 0))
     ref = F.conv1d(x.transpose(1, 2).double(), w.double(), stride=s)
     ref = (0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))).transpose(1, 2).reshape(B * Tout, Cc)
     assert rel_l2(out, ref) < 1e-6
@@ -109,8 +112,8 @@ def test_conv0_groupnorm_gelu(lengths, oracle):
     T0 = (L - 10) // 5 + 1
     out = torch.empty(B, T0, 512, device="cuda")
     scratch = torch.empty(lib().loco_conv0_scratch_bytes(B), dtype=torch.uint8, device="cuda")
-    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), B, L, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out),
-                                      ptr(scratch), stream()))
+    xd, wd, gwd, gbd = dev(x), dev(w.reshape(512, 10)), dev(gw), dev(gb)
+    check(lib().loco_op_conv0_gn_gelu(ptr(xd), B, L, ptr(wd), ptr(gwd), ptr(gbd), ptr(out), ptr(scratch), stream()))
     h = F.conv1d(torch.from_numpy(x).double()[:, None], torch.from_numpy(w).double(), stride=5)
     mean = h.mean(2, keepdim=True)
     var = ((h - mean) ** 2).mean(2, keepdim=True)
@@ -119,8 +122,7 @@ def test_conv0_groupnorm_gelu(lengths, oracle):
     assert rel_l2(out, ref) < 2e-6
     # bitwise reproducible (fixed-order fp64 reduction)
     out2 = torch.empty_like(out)
-    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), B, L, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out2),
-                                      ptr(scratch), stream()))
+    check(lib().loco_op_conv0_gn_gelu(ptr(xd), B, L, ptr(wd), ptr(gwd), ptr(gbd), ptr(out2), ptr(scratch), stream()))
     assert torch.equal(out, out2)
 
 
@@ -133,8 +135,8 @@ def test_conv0_dc_offset_is_stable():
     T0 = (8000 - 10) // 5 + 1
     out = torch.empty(1, T0, 512, device="cuda")
     scratch = torch.empty(lib().loco_conv0_scratch_bytes(1), dtype=torch.uint8, device="cuda")
-    check(lib().loco_op_conv0_gn_gelu(ptr(dev(x)), 1, 8000, ptr(dev(w.reshape(512, 10))), ptr(dev(gw)), ptr(dev(gb)), ptr(out),
-                                      ptr(scratch), stream()))
+    xd, wd, gwd, gbd = dev(x), dev(w.reshape(512, 10)), dev(gw), dev(gb)
+    check(lib().loco_op_conv0_gn_gelu(ptr(xd), 1, 8000, ptr(wd), ptr(gwd), ptr(gbd), ptr(out), ptr(scratch), stream()))
     h = F.conv1d(torch.from_numpy(x).double()[:, None], torch.from_numpy(w).double(), stride=5)
     h = (h - h.mean(2, keepdim=True)) / torch.sqrt(h.var(2, unbiased=False, keepdim=True) + 1e-5)
     h = h * torch.from_numpy(gw).double()[None, :, None] + torch.from_numpy(gb).double()[None, :, None]
@@ -149,7 +151,8 @@ def test_frame_counts(oracle):
     for i, n in enumerate(lens):
         m[i, :n] = 1
     fr = torch.empty(len(lens), dtype=torch.int32, device="cuda")
-    check(lib().loco_op_frame_counts(ptr(m.cuda()), len(lens), L, ptr(fr), stream()))
+    md = m.cuda()
+    check(lib().loco_op_frame_counts(ptr(md), len(lens), L, ptr(fr), stream()))
     assert fr.cpu().tolist() == [oracle.feat_extract_output_lengths(n) for n in lens]
     check(lib().loco_op_frame_counts(None, len(lens), L, ptr(fr), stream()))
     assert fr.cpu().tolist() == [oracle.feat_extract_output_lengths(L)] * len(lens)
@@ -170,8 +173,9 @@ def test_pos_conv_and_sinusoid(B, T, frames, oracle):
     tab = la.sinusoid_table(T + 2)
     fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
     out = torch.empty(B, T, 768, device="cuda")
-    check(lib().loco_op_pos_conv(ptr(dev(h)), ptr(dev(wf)), ptr(dev(bias)), ptr(dev(tab)),
-                                 ptr(fr.cuda()) if fr is not None else None, ptr(out), B, T, stream()))
+    hd, wfd, bd, td = dev(h), dev(wf), dev(bias), dev(tab)
+    frd = fr.cuda() if fr is not None else None
+    check(lib().loco_op_pos_conv(ptr(hd), ptr(wfd), ptr(bd), ptr(td), ptr(frd), ptr(out), B, T, stream()))
     w = oracle.pos_conv_weight(sd).double()
     pc = F.conv1d(h.double().transpose(1, 2), w, bias.double(), padding=64, groups=16)[:, :, :-1]
     ref = h.double() + (0.5 * pc * (1 + torch.erf(pc / math.sqrt(2)))).transpose(1, 2)
@@ -193,7 +197,9 @@ def test_attention_core(B, T, frames, oracle):
     qp = (q @ pe_k.t()).contiguous()  # [B,12,T,320]
     fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
     ctx = torch.empty(B, T, 768, device="cuda")
-    check(lib().loco_op_attention(ptr(dev(qkv)), ptr(dev(qp)), ptr(fr.cuda()) if fr is not None else None, ptr(ctx), B, T, stream()))
+    qkvd, qpd = dev(qkv), dev(qp)
+    frd = fr.cuda() if fr is not None else None
+    check(lib().loco_op_attention(ptr(qkvd), ptr(qpd), ptr(frd), ptr(ctx), B, T, stream()))
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None if fr is None else fr.long(), q_block=128)
     ref = ref.transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 3e-6
@@ -213,6 +219,7 @@ def test_attention_forces_online_softmax_rescale(oracle):
     v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
     qp = (q @ pe_k.t()).contiguous()
     ctx = torch.empty(B, T, 768, device="cuda")
-    check(lib().loco_op_attention(ptr(dev(qkv)), ptr(dev(qp)), None, ptr(ctx), B, T, stream()))
+    qkvd, qpd = dev(qkv), dev(qp)
+    check(lib().loco_op_attention(ptr(qkvd), ptr(qpd), None, ptr(ctx), B, T, stream()))
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None).transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 3e-6
