@@ -13,11 +13,16 @@
 // probe), gfx950 has no xf32, so fp32-in MFMA is the matrix-core path for this workload.
 //
 // Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA
-// tiles (64 accumulator VGPRs).  A/W tiles are staged global -> registers -> LDS (float4), the next
-// k-tile's global loads are issued before the current tile's MFMAs (software prefetch, two LDS buffers,
-// one barrier per k-tile).  The 32x32x2 instruction consumes k = {lane>>5}; we let lane-half h own the
-// contiguous k range [16h, 16h+16) of the tile so that fragments are read with ds_read_b128.  LDS rows
-// are padded to 36 floats: a 16-lane ds_read_b128 group then covers all 64 banks exactly once.
+// tiles (64 accumulator VGPRs), 2 workgroups per CU.  A/W tiles are staged global -> registers -> LDS
+// (16-byte accesses) through two LDS buffers with one barrier per k-tile.  Three levels of software
+// pipelining, each measured on the encoder's shapes (MI355X, QKV GEMM 47968x2304x768):
+//   global loads TWO k-tiles ahead (two register sets)         116 -> 128 TFLOP/s together with
+//   LDS fragments a quarter tile ahead, last quarter after the barrier
+//   D = W_tile * A_tile^T so a lane owns 4 consecutive n       95 -> 120 TFLOP/s on the N=768 GEMMs
+//   -> 16-byte epilogue stores (the dword store tail was issue-bound)
+// The 32x32x2 instruction consumes k = {lane>>5}; lane-half h owns the contiguous k range [16h, 16h+16) of
+// the tile so that fragments are read with ds_read_b128.  LDS rows are padded to 36 floats: a 16-lane
+// ds_read_b128 group then covers all 64 banks exactly once.
 //
 // Block -> tile map is XCD-aware: blocks b and b+8 share an XCD (and its private 4 MiB L2), so each XCD
 // is given a contiguous run of tiles with n fastest -- every n-tile of one A row-panel is computed on
@@ -102,65 +107,118 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     }
     __syncthreads();
 
-    const int nk = p.K / BK;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                ra4[q] = *reinterpret_cast<const f32x4*>(ga[q] + (long)(kt + 1) * BK);
-                rw4[q] = *reinterpret_cast<const f32x4*>(gw[q] + (long)(kt + 1) * BK);
-            }
-        }
-        const float* la = lds[cur] + (wm * 64 + r) * LDT + 16 * h;
-        const float* lw = lds[cur] + (BM + wn * 64 + r) * LDT + 16 * h;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(la + k4 * 4);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(la + 32 * LDT + k4 * 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(lw + k4 * 4);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(lw + 32 * LDT + k4 * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[1][1], 0, 0, 0);
-            }
-        }
-        if (more) {
-            float* na = lds[cur ^ 1];
-            float* nw = lds[cur ^ 1] + BM * LDT;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<f32x4*>(na + (srow + 32 * q) * LDT + sk) = ra4[q];
-                *reinterpret_cast<f32x4*>(nw + (srow + 32 * q) * LDT + sk) = rw4[q];
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
+    // fragment offsets of this lane inside a buffer (floats): A rows wm*64 + {0,32} + r, W rows BM + wn*64 + {0,32} + r
+    const int fa = (wm * 64 + r) * LDT + 16 * h;
+    const int fw = (BM + wn * 64 + r) * LDT + 16 * h;
+
+#define LOCO_LOAD_FRAGS(buf, k4, A0, A1, B0, B1)                                        \
+    A0 = *reinterpret_cast<const f32x4*>((buf) + fa + (k4) * 4);                        \
+    A1 = *reinterpret_cast<const f32x4*>((buf) + fa + 32 * LDT + (k4) * 4);             \
+    B0 = *reinterpret_cast<const f32x4*>((buf) + fw + (k4) * 4);                        \
+    B1 = *reinterpret_cast<const f32x4*>((buf) + fw + 32 * LDT + (k4) * 4);
+#define LOCO_MFMA16(A0, A1, B0, B1)                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0[e], A0[e], acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1[e], A0[e], acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0[e], A1[e], acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1[e], A1[e], acc[1][1], 0, 0, 0); \
     }
 
-    // epilogue: acc[i][j][e] is C[row = (e&3) + 8*(e>>2) + 4*h][col = r] of the 32x32 sub-tile
+    // Software pipeline, skewed by a quarter tile: the fragments of quarter q+1 are read while the 16 MFMAs
+    // of quarter q issue, and the LAST quarter of tile kt is computed AFTER the barrier that publishes tile
+    // kt+1 -- its 1024 MFMA cycles cover the barrier skew and the LDS latency of the next tile's first
+    // fragments, so a wave never waits on LDS with an idle matrix pipe.
+    const int nk = p.K / BK;
+    int cur = 0;
+    f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+    f32x4 rc4[4], rd4[4];  // second staging set: global loads run TWO k-tiles ahead of the MFMAs
+    LOCO_LOAD_FRAGS(lds[0], 0, xa0, xa1, xb0, xb1)
+    if (nk > 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ra4[q] = *reinterpret_cast<const f32x4*>(ga[q] + BK);
+            rw4[q] = *reinterpret_cast<const f32x4*>(gw[q] + BK);
+        }
+    }
+
+#define LOCO_KTILE(SA, SW, NA, NW)                                                              \
+    {                                                                                           \
+        const bool more = kt + 1 < nk;                                                          \
+        if (kt + 2 < nk) {                                                                      \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+                NA[q] = *reinterpret_cast<const f32x4*>(ga[q] + (long)(kt + 2) * BK);           \
+                NW[q] = *reinterpret_cast<const f32x4*>(gw[q] + (long)(kt + 2) * BK);           \
+            }                                                                                   \
+        }                                                                                       \
+        const float* lb = lds[cur];                                                             \
+        LOCO_LOAD_FRAGS(lb, 1, ya0, ya1, yb0, yb1)                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_MFMA16(xa0, xa1, xb0, xb1)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_LOAD_FRAGS(lb, 2, xa0, xa1, xb0, xb1)                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_LOAD_FRAGS(lb, 3, ya0, ya1, yb0, yb1)                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_MFMA16(xa0, xa1, xb0, xb1)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        if (more) {                                                                             \
+            float* na = lds[cur ^ 1];                                                           \
+            float* nw = lds[cur ^ 1] + BM * LDT;                                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
+                *reinterpret_cast<f32x4*>(na + (srow + 32 * q) * LDT + sk) = SA[q];             \
+                *reinterpret_cast<f32x4*>(nw + (srow + 32 * q) * LDT + sk) = SW[q];             \
+            }                                                                                   \
+        }                                                                                       \
+        __syncthreads();                                                                        \
+        cur ^= 1;                                                                               \
+        if (more) { LOCO_LOAD_FRAGS(lds[cur], 0, xa0, xa1, xb0, xb1) }                          \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+    }
+
+    // Software pipeline (see header): global loads two k-tiles ahead (two register sets, loop unrolled by 2),
+    // LDS fragments a quarter tile ahead, last quarter computed after the barrier.
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        LOCO_KTILE(ra4, rw4, rc4, rd4)
+        ++kt;
+        LOCO_KTILE(rc4, rd4, ra4, rw4)
+        --kt;
+    }
+    if (kt < nk) LOCO_KTILE(ra4, rw4, rc4, rd4)
+#undef LOCO_KTILE
+#undef LOCO_LOAD_FRAGS
+#undef LOCO_MFMA16
+
+    // epilogue.  The MFMAs were issued as D = W_tile * A_tile^T, so acc[i][j][e] is
+    //   C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]:
+    // each lane owns 4 consecutive n per register quad -> 16-byte stores (16 per sub-tile pair instead of 64
+    // dword stores; the store tail of a 128x128 tile is issue-bound, not bandwidth-bound).
     float* __restrict__ C = p.C + coff;
     const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + r;
+        if (m >= p.M) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int mb = m0 + wm * 64 + i * 32 + 4 * h;
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    if (EPI == kEpiGelu) v = gelu_erf(v);
-                    if (EPI == kEpiResidual) v += R[(long)m * p.ldr + n];
-                    C[(long)m * p.ldc + n] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                if (n < p.N) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (EPI == kEpiGelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
+                    *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = v;
                 }
             }
         }
@@ -170,21 +228,24 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % BK != 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.sA1 | a.sA2) & 3) return hipErrorInvalidValue;  // float4 staging
+    if ((a.N | a.ldc | a.sC1 | a.sC2) & 3) return hipErrorInvalidValue;    // float4 epilogue
+    if (a.epilogue == kEpiResidual && (a.ldr & 3)) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.W)) & 15) return hipErrorInvalidValue;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const long nblk = (long)tiles_m * tiles_n * a.nb1 * a.nb2;
     if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblk), block(kGemmThreads);
+#define LAUNCH(EPI) hipLaunchKernelGGL((gemm_f32_kernel<EPI>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
     switch (a.epilogue) {
         case kEpiNone:
-            hipLaunchKernelGGL(gemm_f32_kernel<kEpiNone>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            LAUNCH(kEpiNone)
             break;
         case kEpiGelu:
-            hipLaunchKernelGGL(gemm_f32_kernel<kEpiGelu>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            LAUNCH(kEpiGelu)
             break;
         case kEpiResidual:
             if (!a.R) return hipErrorInvalidValue;
-            hipLaunchKernelGGL(gemm_f32_kernel<kEpiResidual>, grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            LAUNCH(kEpiResidual)
             break;
         default:
             return hipErrorInvalidValue;
