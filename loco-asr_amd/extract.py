@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Drop-in for the audio branch of the reference's extraction scripts
+(/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:96-113 and
+extract_speecht5_finetuned_embeddings_slurp.py:93-113) on MI355X.
+
+    python loco-asr_amd/extract.py -m audio -s train                       # SLURP layout under ./slurp
+    python loco-asr_amd/extract.py -m audio -s devel --synthetic 64        # no corpus: seeded synthetic clips
+    torchrun --standalone --nproc-per-node 8 loco-asr_amd/extract.py -m audio -s train     # data parallel
+
+Same flags (-m/--modality, -s/--split), same folder layout (extracted/<model>/<split>/<modality>/) and the same
+per-utterance pickle as the reference; the encoder is the HIP implementation behind the C ABI.  What differs,
+by necessity: weights come from ``--prenet-state-dict`` / ``--encoder-state-dict`` (the pickled dicts the
+base script loads from extracted/speecht5/mapping/, …base…py:40-49) or ``--random-init`` -- there is no
+network for ``from_pretrained``; audio decoding uses soundfile or scipy (librosa is not installed) and
+polyphase resampling to 16 kHz; ``-m text`` is refused (the text prenet is outside this hot path).
+With WORLD_SIZE > 1 the utterances are sharded over ranks (dp.shard_units); each rank writes the files of its
+own shard, so no embedding crosses the fabric unless --gather is given.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+la = importlib.import_module("loco-asr_amd")
+dp = importlib.import_module("loco-asr_amd.dp")
+sink_mod = importlib.import_module("loco-asr_amd.sink")
+
+
+def read_slurp_split(data_path: str, split: str):
+    """(slurp_id, sentence, wav_path, 16000, intent) per utterance, the tuple contract of the reference's
+    SLURPDataset (slurp_data.py:19-66): headset recording if there is one, else the first."""
+    text_path = os.path.join(data_path, "dataset/slurp", split + ".jsonl")
+    audio_dir = os.path.join(data_path, "audio", "slurp_synth" if split == "train_synthetic" else "slurp_real")
+    items = []
+    with open(text_path) as fh:
+        for line in fh:
+            if not line.strip():
+                continue
+            item = json.loads(line)
+            rec = next((r["file"] for r in item["recordings"] if "headset" in r), item["recordings"][0]["file"])
+            items.append((item["slurp_id"], item["sentence"], os.path.join(audio_dir, rec), 16000, item["intent"]))
+    return items
+
+
+def load_audio_16k(path: str) -> np.ndarray:
+    """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56)."""
+    try:
+        import soundfile as sf
+        x, sr = sf.read(path, dtype="float32", always_2d=True)
+        x = x.mean(axis=1)
+    except ImportError:
+        from scipy.io import wavfile
+        if not path.lower().endswith(".wav"):
+            raise RuntimeError(f"cannot decode {path}: install soundfile for FLAC, or convert to WAV")
+        sr, x = wavfile.read(path)
+        if x.dtype.kind == "i":
+            x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+        x = x.astype(np.float32)
+        if x.ndim == 2:
+            x = x.mean(axis=1)
+    if sr != 16000:
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(sr), 16000)
+        x = resample_poly(x, 16000 // g, int(sr) // g).astype(np.float32)
+    return x
+
+
+def one_hot_encoder(classes):
+    """LabelEncoder + LabelBinarizer of the reference (…base…py:32-36): classes sorted, one-hot int64 rows."""
+    order = sorted(set(classes))
+    index = {c: i for i, c in enumerate(order)}
+    eye = np.eye(len(order), dtype=np.int64)
+    return lambda labels: np.stack([eye[index[l]] for l in labels])
+
+
+def load_state_dict_file(path):
+    with open(path, "rb") as fh:
+        sd = pickle.load(fh)
+    return {k: (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))) for k, v in sd.items()}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Extract SpeechT5 speech-encoder embeddings on MI355X")
+    ap.add_argument("--modality", "-m", choices=["text", "audio"], required=True)
+    ap.add_argument("--split", "-s", choices=["train", "devel", "test", "train_synthetic"], required=True)
+    ap.add_argument("--data-path", default="slurp")
+    ap.add_argument("--out", default=os.path.join("extracted", "speecht5_base"))
+    ap.add_argument("--batch-size", type=int, default=16)
+    ap.add_argument("--prenet-state-dict", default="extracted/speecht5/mapping/speech_prenet_state_dict.pickle")
+    ap.add_argument("--encoder-state-dict", default="extracted/speecht5/mapping/encoder_state_dict.pickle")
+    ap.add_argument("--random-init", action="store_true", help="deterministic synthetic weights (no checkpoint available)")
+    ap.add_argument("--synthetic", type=int, default=0, help="encode N seeded synthetic clips instead of a corpus")
+    ap.add_argument("--synthetic-seconds", type=float, default=5.0)
+    ap.add_argument("--classes-file", default=None, help="one intent label per line (the reference's ALL_CLASSES)")
+    ap.add_argument("--do-normalize", action="store_true")
+    ap.add_argument("--format", choices=["pickle", "npy"], default="pickle")
+    ap.add_argument("--gather", action="store_true", help="all-gather embeddings so that rank 0 writes everything")
+    args = ap.parse_args(argv)
+    if args.modality == "text":
+        raise SystemExit("-m text: the text prenet path is outside the MI355X hot path (SURVEY.md §2a rows 1-2)")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    print(f"Extracting {args.modality} embeddings from SLURP {args.split} set using SpeechT5 (rank {rank}/{world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("no ROCm device: this extractor has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    print("Running on", device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    # ---- utterances
+    if args.synthetic:
+        n = int(args.synthetic_seconds * 16000)
+        lens = la.synth.mixed_lengths(args.synthetic, n)
+        items = [(f"synthetic-{i:06d}", "", None, 16000, f"class_{i % 101:03d}") for i in range(args.synthetic)]
+        classes = [f"class_{i:03d}" for i in range(101)]
+        fetch = lambda i: la.synth.clip(i, lens[i])
+        lengths = lens
+    else:
+        items = read_slurp_split(args.data_path, args.split)
+        if args.classes_file:
+            classes = [l.strip() for l in open(args.classes_file) if l.strip()]
+        else:
+            classes = sorted({it[4] for it in items})
+        fetch = lambda i: load_audio_16k(items[i][2])
+        lengths = [0] * len(items)  # unknown until decoded: keep corpus order within a rank
+    print(f"{args.split} set size: {len(items)}")
+    encode_labels = one_hot_encoder(classes)
+
+    # ---- model
+    if args.random_init:
+        pre, enc_sd = la.synth.split_state_dict(la.synth.encoder_state_dict(0))
+        pre = {k: torch.from_numpy(v) for k, v in pre.items()}
+        enc_sd = {k: torch.from_numpy(v) for k, v in enc_sd.items()}
+    else:
+        pre, enc_sd = load_state_dict_file(args.prenet_state_dict), load_state_dict_file(args.encoder_state_dict)
+    model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts(pre, enc_sd).to(device)
+    print("Loaded model")
+    model.eval()
+    processor = la.SpeechT5FeatureExtractorMI355X(do_normalize=args.do_normalize, pin_memory=True)
+
+    shards = [dp.shard_units(lengths, world, r) if any(lengths) else list(range(r, len(items), world)) for r in range(world)]
+    mine = shards[rank]
+    n_rounds = (max(len(s) for s in shards) + args.batch_size - 1) // args.batch_size  # equal on all ranks: collectives line up
+    with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
+        for rnd in range(n_rounds):
+            idx = mine[rnd * args.batch_size:(rnd + 1) * args.batch_size]
+            emb = torch.zeros((0, 1, 768), dtype=torch.float32, device=device)
+            if idx:
+                audios = processor(audio=[fetch(i) for i in idx], sampling_rate=16000, return_tensors="pt", padding="longest").to(device)
+                emb = model.speecht5.encoder(**audios).last_hidden_state
+            if args.gather and world > 1:
+                embs = dp.gather_ragged(emb, idx, len(items))  # the one large collective of the step
+                if rank == 0:
+                    for gid, e in enumerate(embs):
+                        if e is not None:
+                            sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
+            elif idx:
+                sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+    print("Done!")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""Host-side pieces that need no GPU: synthetic data determinism, the feature-extractor mirror, the pickle sink
+and its reader, unit sharding."""
+import importlib
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+la = importlib.import_module("loco-asr_amd")
+dp = importlib.import_module("loco-asr_amd.dp")
+sink = importlib.import_module("loco-asr_amd.sink")
+extract = importlib.import_module("loco-asr_amd.extract")
+
+
+def test_synth_is_pinned():
+    """The hash generator must never drift: goldens depend on it."""
+    u = la.synth.hashed_uniform("pin", (4,), 0)
+    assert u.dtype == np.float32
+    np.testing.assert_array_equal(u, la.synth.hashed_uniform("pin", (4,), 0))
+    assert not np.array_equal(u, la.synth.hashed_uniform("pin", (4,), 1))
+    sd = la.synth.encoder_state_dict(0, layers=1)
+    w = sd["wrapped_encoder.layers.0.attention.q_proj.weight"]
+    assert w.shape == (768, 768) and abs(float(w.std()) - 1.5 / np.sqrt(768)) < 2e-3
+    c = la.synth.clip(0, 1000)
+    assert c.dtype == np.float32 and c.shape == (1000,)
+    np.testing.assert_array_equal(c, la.synth.clip(0, 1000))
+    assert la.synth.mixed_lengths(3, 480000) == la.synth.mixed_lengths(3, 480000)
+    # first values pinned (a change here invalidates every fixture in tests/golden/)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g1_1s.npz"))
+    assert int(g["lengths"][0]) == 16000
+
+
+def test_feature_extractor_pads_and_masks():
+    fe = la.SpeechT5FeatureExtractorMI355X()
+    clips = [la.synth.clip(0, 1000), la.synth.clip(1, 640)]
+    out = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+    assert out["input_values"].shape == (2, 1000) and out["input_values"].dtype == torch.float32
+    assert out["attention_mask"].dtype == torch.int32
+    assert out.attention_mask.sum(1).tolist() == [1000, 640]
+    assert float(out.input_values[1, 640:].abs().max()) == 0.0
+    np.testing.assert_array_equal(out.input_values[1, :640].numpy(), clips[1])
+    with pytest.raises(ValueError):
+        fe(audio=clips, sampling_rate=8000)
+    with pytest.raises(ValueError):
+        fe(audio=None)
+    kw = dict(**out)  # usable as encoder(**audios)
+    assert set(kw) == {"input_values", "attention_mask"}
+
+
+def test_feature_extractor_matches_hf_when_available():
+    tr = pytest.importorskip("transformers")
+    clips = [la.synth.clip(0, 2000), la.synth.clip(1, 1234), la.synth.clip(2, 777)]
+    for norm in (False, True):
+        hf = tr.SpeechT5FeatureExtractor(do_normalize=norm)(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        ours = la.SpeechT5FeatureExtractorMI355X(do_normalize=norm)(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        assert torch.equal(hf["attention_mask"].to(torch.int32), ours["attention_mask"])
+        torch.testing.assert_close(hf["input_values"], ours["input_values"], rtol=1e-6, atol=1e-6)
+
+
+def test_sink_writes_the_reference_format(tmp_path):
+    emb = torch.randn(3, 7, 768)
+    tg = np.eye(101, dtype=np.int64)[[5, 0, 100]]
+    with sink.EmbeddingSink(str(tmp_path), "devel", "audio") as s:
+        s.submit(["a-1", "b-2", 33], emb, tg)
+    folder = tmp_path / "devel" / "audio"
+    assert sorted(os.listdir(folder)) == ["33_embedding_and_target.pickle", "a-1_embedding_and_target.pickle", "b-2_embedding_and_target.pickle"]
+    with open(folder / "b-2_embedding_and_target.pickle", "rb") as fh:
+        d = pickle.load(fh)
+    assert set(d) == {"id", "embedding", "target"} and d["id"] == "b-2"
+    assert d["embedding"].dtype == np.float32 and d["embedding"].shape == (7, 768)
+    np.testing.assert_array_equal(d["embedding"], emb[1].numpy())
+    assert d["target"].shape == (101,) and d["target"][0] == 1
+    # the reader restating SLURPEmbeddingsTargets (slurp_embeddings_and_targets.py:19-28) consumes it
+    ds = sink.EmbeddingsTargets(str(tmp_path), modality="audio", split="devel")
+    assert len(ds) == 3
+    sid, e, t = ds[0]
+    assert torch.is_tensor(e) and e.shape == (7, 768) and t.shape == (101,)
+
+
+def test_sink_npy_format(tmp_path):
+    with sink.EmbeddingSink(str(tmp_path), "test", "audio", fmt="npy") as s:
+        s.submit(["x"], torch.ones(1, 2, 768), [np.zeros(101, np.int64)])
+    assert np.load(tmp_path / "test" / "audio" / "x.embedding.npy").shape == (2, 768)
+
+
+def test_one_hot_encoder_matches_sklearn():
+    sk = pytest.importorskip("sklearn.preprocessing")
+    classes = ["b", "a", "d", "c", "e"]
+    le = sk.LabelEncoder()
+    lb = sk.LabelBinarizer()
+    lb.fit_transform(le.fit_transform(classes))
+    labels = ["c", "a", "e"]
+    np.testing.assert_array_equal(extract.one_hot_encoder(classes)(labels), lb.transform(le.transform(labels)))
+
+
+def test_shard_units_balances_and_partitions():
+    lengths = [480000, 16000, 300000, 80000, 80000, 9600000, 1000, 48000, 123456]
+    for world in (1, 2, 3, 8):
+        shards = [dp.shard_units(lengths, world, r) for r in range(world)]
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(len(lengths)))
+        assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    # longest first, dealt round-robin: the two longest land on different ranks
+    s0, s1 = dp.shard_units(lengths, 2, 0), dp.shard_units(lengths, 2, 1)
+    assert (5 in s0) != (0 in s0)
+
+
+def test_slurp_reader_contract(tmp_path):
+    root = tmp_path / "slurp"
+    (root / "dataset" / "slurp").mkdir(parents=True)
+    (root / "audio" / "slurp_real").mkdir(parents=True)
+    rows = [{"slurp_id": 7, "sentence": "wake me at five", "intent": "alarm_set",
+             "recordings": [{"file": "audio-1.flac"}, {"file": "audio-1-headset.flac", "headset": True}]},
+            {"slurp_id": 9, "sentence": "stop", "intent": "audio_volume_mute", "recordings": [{"file": "audio-2.flac"}]}]
+    import json
+    (root / "dataset" / "slurp" / "devel.jsonl").write_text("\n".join(json.dumps(r) for r in rows) + "\n")
+    items = extract.read_slurp_split(str(root), "devel")
+    assert [i[0] for i in items] == [7, 9]
+    assert items[0][2].endswith("audio-1-headset.flac") and items[1][2].endswith("audio-2.flac")
+    assert items[0][3] == 16000 and items[0][4] == "alarm_set"
