@@ -146,14 +146,23 @@ def main():
                                "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 and s["flops"] else None,
                                "gbps": (s["bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 and s["bytes"] else None}
                    for s in stats}
+        traffic = None
+        try:  # PMC HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_traffic.json")))
+            if tf:
+                traffic = json.load(open(tf[-1]))["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = None
         if g and g["ms"] > 0:
             ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
             roofline = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                         "launches_per_step": g["launches"] / args.steps,
                         "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                        "flops_per_launch_avg": g["flops"] / g["launches"]}
+                        "flops_per_launch_avg": g["flops"] / g["launches"],
+                        "algorithmic_bytes_per_launch_avg": g["bytes"] / g["launches"]}
         whole = flops_per_clip(T) * B * world * args.steps / elapsed / 1e12
         result = {
             "metric": "audio frames/sec SpeechT5-base encoder, 30s×bs32 @1/2/4/8 GPU; embed L2 vs HF",

@@ -1,0 +1,47 @@
+"""The drop-in extraction CLI end to end on one MI355X: synthetic clips -> encoder -> asynchronous sink -> the
+reference's per-utterance pickle, read back with the reader that restates SLURPEmbeddingsTargets and checked
+against the CPU oracle."""
+import importlib
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extract_cli_synthetic(tmp_path, oracle):
+    la = importlib.import_module("loco-asr_amd")
+    extract = importlib.import_module("loco-asr_amd.extract")
+    sink = importlib.import_module("loco-asr_amd.sink")
+    out = str(tmp_path / "extracted" / "speecht5_base")
+    extract.main(["-m", "audio", "-s", "devel", "--synthetic", "5", "--synthetic-seconds", "1.5", "--random-init",
+                  "--batch-size", "2", "--out", out])
+    ds = sink.EmbeddingsTargets(out, modality="audio", split="devel")
+    assert len(ds) == 5
+    n = int(1.5 * 16000)
+    lens = la.synth.mixed_lengths(5, n)
+    sd = la.synth.encoder_state_dict(0)
+    fe = la.SpeechT5FeatureExtractorMI355X()
+    # batches are formed over the corpus order dealt by dp.shard_units (single rank: longest first)
+    dp = importlib.import_module("loco-asr_amd.dp")
+    order = dp.shard_units(lens, 1, 0)
+    for b0 in range(0, 5, 2):
+        idx = order[b0:b0 + 2]
+        b = fe(audio=[la.synth.clip(i, lens[i]) for i in idx], sampling_rate=16000)
+        ref = oracle.encode(b["input_values"], b["attention_mask"], sd)
+        for row, i in enumerate(idx):
+            with open(os.path.join(out, "devel", "audio", f"synthetic-{i:06d}_embedding_and_target.pickle"), "rb") as fh:
+                d = pickle.load(fh)
+            assert d["embedding"].shape == tuple(ref[row].shape) and d["embedding"].dtype == np.float32
+            rel = np.linalg.norm(d["embedding"] - ref[row].numpy()) / np.linalg.norm(ref[row].numpy())
+            assert rel < 1e-4
+            assert d["target"].shape == (101,) and d["target"].sum() == 1 and d["target"][i % 101] == 1
+
+
+def test_text_modality_is_refused():
+    extract = importlib.import_module("loco-asr_amd.extract")
+    with pytest.raises(SystemExit):
+        extract.main(["-m", "text", "-s", "devel"])
