@@ -232,3 +232,91 @@ def encode(input_values, attention_mask, sd, dtype=torch.float32, q_block=512, t
     m = None if attention_mask is None else torch.as_tensor(attention_mask)
     h, frames = speech_prenet(x, m, sd, "prenet.", dtype, taps)
     return wrapped_encoder(h, frames, sd, "wrapped_encoder.", dtype, q_block, hidden_states)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Probe-row variants: the same maths restricted to a few output rows, so that 10-minute inputs (T = 29 999,
+# BASELINE.json configs[2]) can be checked in seconds.  They take the stage INPUT (as produced by the
+# implementation under test) and return the stage output for the probe rows only.
+
+@torch.no_grad()
+def encoder_layer_rows(x, rows, frames, sd, lp, pe_k, dtype=torch.float64):
+    """Output rows `rows` of SpeechT5EncoderLayer (HF:1027-1067) for ONE clip x [T,768]; K/V use all T frames."""
+    x = torch.as_tensor(x).to(dtype)
+    T, D = x.shape
+    H, dh = HEADS, D // HEADS
+    rows = torch.as_tensor(rows, dtype=torch.long)
+    xr = x[rows]
+    q = F.linear(xr, _t(sd, lp + "attention.q_proj.weight", dtype), _t(sd, lp + "attention.q_proj.bias", dtype)) * dh ** -0.5
+    k = F.linear(x, _t(sd, lp + "attention.k_proj.weight", dtype), _t(sd, lp + "attention.k_proj.bias", dtype))
+    v = F.linear(x, _t(sd, lp + "attention.v_proj.weight", dtype), _t(sd, lp + "attention.v_proj.bias", dtype))
+    q = q.view(-1, H, dh).transpose(0, 1)  # [H,R,dh]
+    k = k.view(T, H, dh).transpose(0, 1)
+    v = v.view(T, H, dh).transpose(0, 1)
+    s = q @ k.transpose(-1, -2)  # [H,R,T]
+    qp = q @ pe_k.to(dtype).t()  # [H,R,320]
+    rel = (rows[:, None] - torch.arange(T)[None, :]).clamp(-REL_MAX, REL_MAX - 1) + REL_MAX
+    s = s + torch.gather(qp, 2, rel[None].expand(H, -1, -1))
+    if frames is not None:
+        s = s.masked_fill((torch.arange(T) >= int(frames))[None, None, :], float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).transpose(0, 1).reshape(len(rows), D)
+    a = F.linear(o, _t(sd, lp + "attention.out_proj.weight", dtype), _t(sd, lp + "attention.out_proj.bias", dtype))
+    h = F.layer_norm(xr + a, (D,), _t(sd, lp + "layer_norm.weight", dtype), _t(sd, lp + "layer_norm.bias", dtype), LN_EPS)
+    f = gelu_erf(F.linear(h, _t(sd, lp + "feed_forward.intermediate_dense.weight", dtype),
+                          _t(sd, lp + "feed_forward.intermediate_dense.bias", dtype)))
+    f = F.linear(f, _t(sd, lp + "feed_forward.output_dense.weight", dtype), _t(sd, lp + "feed_forward.output_dense.bias", dtype))
+    return F.layer_norm(h + f, (D,), _t(sd, lp + "final_layer_norm.weight", dtype),
+                        _t(sd, lp + "final_layer_norm.bias", dtype), LN_EPS)
+
+
+@torch.no_grad()
+def feature_encoder_window(x, sd, frame_lo, frame_hi, prefix="prenet.", dtype=torch.float64):
+    """Frames [frame_lo, frame_hi) of the conv stack (HF:484-494) for ONE clip x [L]: GroupNorm statistics over the
+    whole clip (conv0 is cheap: 1 GFLOP per 30 s), layers 1-6 only on the window's receptive field."""
+    x = torch.as_tensor(x).to(dtype)[None, None]
+    w0 = _t(sd, prefix + "feature_encoder.conv_layers.0.conv.weight", dtype)
+    # statistics in chunks to bound memory
+    n0 = (x.shape[-1] - 10) // 5 + 1
+    s1 = torch.zeros(512, dtype=torch.float64)
+    s2 = torch.zeros(512, dtype=torch.float64)
+    step = 200000
+    for t0 in range(0, n0, step):
+        t1 = min(n0, t0 + step)
+        y = F.conv1d(x[..., 5 * t0:5 * (t1 - 1) + 10], w0, stride=5)[0].double()
+        s1 += y.sum(1)
+        s2 += (y * y).sum(1)
+    mean = (s1 / n0)
+    var = s2 / n0 - mean * mean
+    # receptive field of frames [lo, hi) back through layers 6..1
+    lo, hi = frame_lo, frame_hi - 1
+    for k, s in reversed(list(zip(CONV_KERNEL[1:], CONV_STRIDE[1:]))):
+        lo, hi = lo * s, hi * s + k - 1
+    y = F.conv1d(x[..., 5 * lo:5 * hi + 10], w0, stride=5)
+    gw = _t(sd, prefix + "feature_encoder.conv_layers.0.layer_norm.weight", dtype)[None, :, None]
+    gb = _t(sd, prefix + "feature_encoder.conv_layers.0.layer_norm.bias", dtype)[None, :, None]
+    y = (y - mean.to(dtype)[None, :, None]) * torch.rsqrt(var.to(dtype) + LN_EPS)[None, :, None] * gw + gb
+    h = gelu_erf(y)
+    for i, (k, s) in enumerate(zip(CONV_KERNEL[1:], CONV_STRIDE[1:]), start=1):
+        h = gelu_erf(F.conv1d(h, _t(sd, f"{prefix}feature_encoder.conv_layers.{i}.conv.weight", dtype), stride=s))
+    assert h.shape[-1] == frame_hi - frame_lo, (h.shape, frame_lo, frame_hi)
+    return h[0].t().contiguous()
+
+
+@torch.no_grad()
+def pos_conv_rows(h, rows, nvalid, sd, prefix="prenet.", dtype=torch.float64):
+    """Rows `rows` of hidden + GELU(pos_conv(hidden)) + sinusoid (HF:555-564) for ONE clip h [T,768]."""
+    h = torch.as_tensor(h).to(dtype)
+    T = h.shape[0]
+    w = pos_conv_weight(sd, prefix, dtype)
+    b = _t(sd, prefix + "pos_conv_embed.conv.bias", dtype)
+    tab = sinusoid_table(T + 3, h.shape[-1], dtype)
+    out = []
+    for r in rows:
+        lo, hi = r - POS_CONV_K // 2, r + POS_CONV_K // 2  # taps read h[r-64 .. r+63]
+        win = torch.zeros(POS_CONV_K, h.shape[1], dtype=dtype)
+        a, bnd = max(lo, 0), min(hi, T)
+        win[a - lo:bnd - lo] = h[a:bnd]
+        pc = F.conv1d(win.t()[None], w, b, groups=POS_CONV_GROUPS)[0, :, 0]
+        pos = r + 2 if r < nvalid else PAD_IDX
+        out.append(h[r] + gelu_erf(pc) + tab[pos])
+    return torch.stack(out)
