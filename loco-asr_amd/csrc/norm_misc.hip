@@ -64,36 +64,58 @@ hipError_t launch_layernorm(const float* x, const float* g, const float* b, floa
 }
 
 // frames[b] = conv-chain output length of sum(mask[b,:])   (HF modeling:569-598; HF uses cumsum(-1)[-1] = the sum)
-__global__ __launch_bounds__(256) void frame_counts_kernel(const int32_t* __restrict__ mask, long L,
-                                                           int32_t* __restrict__ frames) {
-    __shared__ long part[4];
-    const int b = blockIdx.x;
-    long n = 0;
-    if (mask) {
-        const int32_t* m = mask + (long)b * L;
-        for (long i = threadIdx.x; i < L; i += 256) n += m[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
-        __syncthreads();
-        n = part[0] + part[1] + part[2] + part[3];
-    } else {
-        n = L;
-    }
-    if (threadIdx.x == 0) {
-        const int ks[7] = {10, 3, 3, 3, 3, 2, 2}, ss[7] = {5, 2, 2, 2, 2, 2, 2};
-        for (int i = 0; i < 7; ++i) {
-            // torch.div(n - k, s, rounding_mode="floor") + 1: floor division also for negative n - k
-            long d = n - ks[i];
-            long qd = d >= 0 ? d / ss[i] : -((-d + ss[i] - 1) / ss[i]);
-            n = qd + 1;
+// Stage 1 streams the mask with 16-byte loads over a (parts, B) grid and adds per-block counts into frames[b]
+// (integer atomics: order-independent, so the result is exact and reproducible); stage 2 converts in place.
+__global__ __launch_bounds__(256) void mask_count_kernel(const int32_t* __restrict__ mask, long L, int32_t* __restrict__ frames) {
+    __shared__ int part[4];
+    const int b = blockIdx.y;
+    const int32_t* m = mask + (long)b * L;
+    const long per = (((L + gridDim.x - 1) / gridDim.x) + 3) & ~3L;
+    const long i0 = (long)blockIdx.x * per;
+    long i1 = i0 + per;
+    i1 = i1 < L ? i1 : L;
+    i1 = i1 < i0 ? i0 : i1;  // blocks past the end contribute nothing
+    int n = 0;
+    if ((reinterpret_cast<uintptr_t>(m) & 15) == 0) {
+        const long v1 = i0 + ((i1 - i0) & ~3L);
+        for (long i = i0 + 4 * threadIdx.x; i < v1; i += 1024) {
+            const int4 v = *reinterpret_cast<const int4*>(m + i);
+            n += (v.x + v.y) + (v.z + v.w);
         }
-        frames[b] = (int32_t)n;
+        for (long i = v1 + threadIdx.x; i < i1; i += 256) n += m[i];
+    } else {
+        for (long i = i0 + threadIdx.x; i < i1; i += 256) n += m[i];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&frames[b], (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ void frames_from_counts_kernel(int32_t* __restrict__ frames, int B, long L, int have_mask) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    long n = have_mask ? (long)frames[b] : L;
+    const int ks[7] = {10, 3, 3, 3, 3, 2, 2}, ss[7] = {5, 2, 2, 2, 2, 2, 2};
+    for (int i = 0; i < 7; ++i) {
+        // torch.div(n - k, s, rounding_mode="floor") + 1: floor division also for negative n - k
+        const long d = n - ks[i];
+        n = (d >= 0 ? d / ss[i] : -((-d + ss[i] - 1) / ss[i])) + 1;
+    }
+    frames[b] = (int32_t)n;
 }
 
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s) {
-    hipLaunchKernelGGL(frame_counts_kernel, dim3(B), dim3(256), 0, s, mask, L, frames);
+    if (B <= 0 || B > 65535) return hipErrorInvalidValue;
+    if (mask) {
+        hipError_t e = hipMemsetAsync(frames, 0, (size_t)B * sizeof(int32_t), s);
+        if (e != hipSuccess) return e;
+        long parts = (L + 65535) / 65536;  // >= 64 Ki samples per block
+        parts = parts < 1 ? 1 : (parts > 256 ? 256 : parts);
+        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)parts, B), dim3(256), 0, s, mask, L, frames);
+    }
+    hipLaunchKernelGGL(frames_from_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, frames, B, L, mask ? 1 : 0);
     return hipGetLastError();
 }
 
