@@ -165,6 +165,33 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
 int loco_op_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
                       void* stream);
 
+/* ---- intent head: the first consumer of the embeddings ("next" row f-1) --------------------------------------
+ * IntentClassifier (/root/reference/speech_text/intent_classifier.py:24-49): pooling over time
+ * (method 0 = average, 1 = max, 2 = learned-query softmax attention, :32-36) + Linear(768,101), and one
+ * optimisation step of train_classifier.py:104-115: soft-label CrossEntropyLoss (mean over the batch) +
+ * Adam with L2 weight decay (:66-68).  Parameters are one flat fp32 vector [q (768) | W (101*768) | b (101)];
+ * gradients use the same layout, so a data-parallel trainer all-reduces ONE 78 437-float buffer between
+ * loco_head_loss_grad and loco_head_adam_step.  x is [B, T, 768] exactly as the reference's collate_fn pads it
+ * (zeros, no mask: padded frames take part in the pooling there too, train_classifier.py:47-50). */
+typedef struct loco_head loco_head;
+const char* loco_head_last_error(void);
+loco_head* loco_head_create(int method);
+void loco_head_destroy(loco_head* head);
+int32_t loco_head_num_params(void); /* 78 437 */
+int loco_head_set_params(loco_head* head, const float* flat); /* host or device; resets the Adam state */
+int loco_head_get_params(const loco_head* head, float* flat);
+size_t loco_head_workspace_bytes(int32_t B, int32_t T);
+/* logits f32 [B,101] (the reference's forward returns [B,1,101]) */
+int loco_head_forward(loco_head* head, const float* x, int32_t B, int32_t T, float* logits, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* forward + backward: loss (device scalar), optional logits [B,101], grads [78 437] (device) */
+int loco_head_loss_grad(loco_head* head, const float* x, const float* target, int32_t B, int32_t T, float* loss,
+                        float* logits, float* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* torch.optim.Adam semantics (weight decay added to the gradient, bias correction); q is left untouched for
+ * methods 0/1, where the reference's q.grad is None */
+int loco_head_adam_step(loco_head* head, const float* grads, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

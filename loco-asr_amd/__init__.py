@@ -10,6 +10,7 @@ from ._lib import LIB_PATH, LocoError  # noqa: F401
 from .encoder import (BaseModelOutput, SpeechT5EncoderWithSpeechPrenetMI355X,  # noqa: F401
                       SpeechT5ForSpeechToTextMI355X, sinusoid_table)
 from .feature_extractor import BatchFeature, SpeechT5FeatureExtractorMI355X  # noqa: F401
+from .intent_head import IntentClassifierMI355X  # noqa: F401
 
 __all__ = ["synth", "LIB_PATH", "LocoError", "BaseModelOutput", "SpeechT5EncoderWithSpeechPrenetMI355X",
-           "SpeechT5ForSpeechToTextMI355X", "sinusoid_table", "BatchFeature", "SpeechT5FeatureExtractorMI355X"]
+           "SpeechT5ForSpeechToTextMI355X", "sinusoid_table", "BatchFeature", "SpeechT5FeatureExtractorMI355X", "IntentClassifierMI355X"]

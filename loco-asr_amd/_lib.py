@@ -55,6 +55,16 @@ SIGNATURES = {
     "loco_op_frame_counts": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "loco_op_pos_conv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "loco_head_last_error": (C.c_char_p, []),
+    "loco_head_create": (_vp, [C.c_int]),
+    "loco_head_destroy": (None, [_vp]),
+    "loco_head_num_params": (_i32, []),
+    "loco_head_set_params": (C.c_int, [_vp, _vp]),
+    "loco_head_get_params": (C.c_int, [_vp, _vp]),
+    "loco_head_workspace_bytes": (_sz, [_i32, _i32]),
+    "loco_head_forward": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "loco_head_loss_grad": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "loco_head_adam_step": (C.c_int, [_vp, _vp, _f, _f, _f, _f, _f, _vp]),
 }
 
 _lib = None

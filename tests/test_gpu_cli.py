@@ -45,3 +45,24 @@ def test_text_modality_is_refused():
     extract = importlib.import_module("loco-asr_amd.extract")
     with pytest.raises(SystemExit):
         extract.main(["-m", "text", "-s", "devel"])
+
+
+def test_extract_then_train_head_pipeline(tmp_path):
+    """configs[4] in miniature: synthetic clips -> encoder -> pickles -> train_head.py (the train_classifier.py
+    drop-in) for two epochs; the head must fit the 8-class toy labels better than chance and write the reference's
+    checkpoint / log files."""
+    extract = importlib.import_module("loco-asr_amd.extract")
+    train_head = importlib.import_module("loco-asr_amd.train_head")
+    root = str(tmp_path / "extracted" / "speecht5_base")
+    for split, n in (("train", 24), ("devel", 8)):
+        extract.main(["-m", "audio", "-s", split, "--synthetic", str(n), "--synthetic-seconds", "1", "--random-init",
+                      "--batch-size", "8", "--out", root])
+    tl, ta = train_head.main(["-m", "audio", "-p", "attention", "-v", "base", "--folder", root, "--epochs", "2",
+                              "--out-root", str(tmp_path)])
+    ck = tmp_path / "checkpoints" / "base" / "audio" / "attention"
+    assert (ck / "speecht5_attention_audio_best.pth").exists() and (ck / "speecht5_attention_audio_last.pth").exists()
+    assert (ck / "speecht5_attention_audio_epoch_2.pth").exists()
+    assert (tmp_path / "results" / "base" / "audio" / "attention" / "logs" / "results.txt").exists()
+    sd = torch.load(ck / "speecht5_attention_audio_best.pth")
+    assert set(sd) == {"q", "classifier.0.weight", "classifier.0.bias"}
+    assert np.isfinite(tl)

@@ -1,0 +1,96 @@
+"""Intent head ("next" row f-1) on the GPU against its torch-autograd oracle: forward logits, loss, every gradient,
+and three Adam steps, for the three pooling methods, with zero-padded ragged batches as the reference's
+collate_fn builds them.  fp32 tolerances: 2e-5 relative on logits/loss/grads, 1e-5 on updated parameters."""
+import importlib
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import la, rel_l2
+    import intent_head_oracle as iho
+
+
+def make_batch(B, T, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, T, 768, generator=g) * 0.8
+    lens = torch.randint(max(1, T // 3), T + 1, (B,), generator=g)
+    lens[0] = T
+    for b in range(B):
+        x[b, lens[b]:] = 0  # pad_sequence zeros
+    cls = torch.randint(0, 101, (B,), generator=g)
+    target = torch.eye(101, dtype=torch.int64)[cls]
+    return x, target
+
+
+def paired(method, seed=0):
+    torch.manual_seed(seed)
+    ref = iho.IntentClassifierOracle(method)
+    with torch.no_grad():
+        ref.q.mul_(300.0)  # make the attention weights non-uniform (q starts at 1e-3 scale)
+    head = la.IntentClassifierMI355X(method)
+    head.load_state_dict(ref.state_dict())
+    return ref, head.to("cuda")
+
+
+@pytest.mark.parametrize("method", ["average", "max", "attention"])
+@pytest.mark.parametrize("B,T", [(16, 250), (3, 1), (5, 129), (2, 700)])
+def test_forward_loss_and_gradients(method, B, T):
+    ref, head = paired(method)
+    x, target = make_batch(B, T, 1)
+    logits = head(x.cuda())
+    assert tuple(logits.shape) == (B, 1, 101)
+    pred = ref(x)
+    assert rel_l2(logits, pred.detach()) < 2e-5
+    loss = torch.nn.CrossEntropyLoss()(pred.squeeze(1), target.float())
+    loss.backward()
+    gl, glogits, grads = head.loss_and_grads(x.cuda(), target.cuda())
+    assert abs(float(gl) - float(loss.detach())) < 2e-5 * max(1.0, abs(float(loss.detach())))
+    gq, gw, gb = grads[:768].cpu(), grads[768:768 + 101 * 768].view(101, 768).cpu(), grads[768 + 101 * 768:].cpu()
+    assert rel_l2(gw, ref.classifier[0].weight.grad) < 2e-5
+    assert rel_l2(gb, ref.classifier[0].bias.grad) < 2e-5
+    if method == "attention":
+        rq = ref.q.grad.reshape(-1)
+        if float(rq.norm()) == 0.0:  # T == 1: softmax over one frame has no gradient
+            assert float(gq.abs().max()) < 1e-7
+        else:
+            assert rel_l2(gq, rq) < 5e-5
+    else:
+        assert ref.q.grad is None and float(gq.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("method", ["average", "max", "attention"])
+def test_three_adam_steps_match_torch(method):
+    ref, head = paired(method, seed=3)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=0.0001)
+    for step in range(3):
+        x, target = make_batch(16, 180, 10 + step)
+        lr_, _ = iho.train_step(ref, opt, x, target)
+        lg, _ = head.train_step(x.cuda(), target.cuda())
+        assert abs(float(lg) - float(lr_)) < 5e-5 * max(1.0, abs(float(lr_))), step
+    sd = head.state_dict()
+    assert rel_l2(sd["classifier.0.weight"], ref.classifier[0].weight.detach()) < 1e-5
+    assert rel_l2(sd["classifier.0.bias"], ref.classifier[0].bias.detach()) < 1e-5
+    assert rel_l2(sd["q"], ref.q.detach()) < 1e-5
+
+
+def test_head_on_real_encoder_output():
+    """extract -> classify without the pickle round trip: the encoder's last_hidden_state feeds the head directly."""
+    from gpu_util import model
+    m, _ = model(layers=2)
+    x, msk = la.synth.batch([16000, 9000])
+    emb = m.speecht5.encoder(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda()).last_hidden_state
+    ref, head = paired("attention")
+    assert rel_l2(head(emb), ref(emb.cpu()).detach()) < 2e-5
+
+
+def test_errors():
+    _, head = paired("max")
+    with pytest.raises(ValueError):
+        head(torch.zeros(2, 5, 512, device="cuda"))
+    with pytest.raises(RuntimeError):
+        head(torch.zeros(2, 5, 768))
