@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
+                    help="GEMM arithmetic: exact fp32 MFMA (default) or fp16 x3 split MFMA (fp32-class accuracy, ~2x faster)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clips", type=int, default=4)
     args = ap.parse_args()
@@ -102,7 +104,8 @@ def main():
     sd = la.synth.encoder_state_dict(0)
     pre, enc_sd = la.synth.split_state_dict(sd)
     model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
-                                                             {k: torch.from_numpy(v) for k, v in enc_sd.items()}).to(dev)
+                                                             {k: torch.from_numpy(v) for k, v in enc_sd.items()},
+                                                             precision=args.precision).to(dev)
     enc = model.speecht5.encoder
     x_np, m_np = la.synth.batch([L] * B, first_index=rank * B)
     x = torch.from_numpy(x_np).to(dev)

@@ -109,6 +109,15 @@ int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_m
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Arithmetic of the GEMMs (conv layers 1-6, feature projection, QKV / out / FFN projections = 90 % of the FLOPs):
+ *   0  exact fp32 (v_mfma_f32_32x32x2_f32)                                       -- default
+ *   1  "f16x3": operands split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
+ *      fp32-class accuracy (embeddings 3e-6 relative L2 of an fp64 evaluation vs 7e-7 for mode 0) at ~2x the speed.
+ * Statistics, softmax, residuals and the attention products stay fp32 in both modes.  Takes effect at the next
+ * loco_forward. */
+int loco_set_precision(loco_encoder* enc, int mode);
+int loco_get_precision(const loco_encoder* enc);
+
 /* Stage taps for parity tests: when set (device pointers, may individually be NULL) the next forwards also
  * copy the conv-stack output [B,T,512], the feature projection [B,T,768] and the prenet output [B,T,768]. */
 int loco_set_taps(loco_encoder* enc, float* conv_stack, float* feature_projection, float* prenet);
@@ -164,6 +173,16 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
  * heads merged.  Flash-style: no [T,T] tensor is ever formed. */
 int loco_op_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
                       void* stream);
+
+/* ---- split-precision ("f16x3") operators: fp32-class accuracy at the fp16 matrix-core rate ----------------------
+ * x = hi + lo with hi = fp16(x), lo = fp16(x - hi); A W^T ~= Ahi Whi^T + Alo Whi^T + Ahi Wlo^T (gemm_f16x3.hip). */
+int loco_op_split_f16(const float* x, void* hi, void* lo, int64_t n, void* stream); /* n % 4 == 0 */
+/* as loco_op_gemm with fp16 hi/lo planes for A and W (lda/ldw % 8 == 0); output fp32 C, or split planes Chi/Clo
+ * when Chi != NULL (the form the next GEMM consumes). */
+int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
+                       const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc,
+                       int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2, int64_t sA1, int64_t sA2,
+                       int64_t sC1, int64_t sC2, void* stream);
 
 /* ---- intent head: the first consumer of the embeddings ("next" row f-1) --------------------------------------
  * IntentClassifier (/root/reference/speech_text/intent_classifier.py:24-49): pooling over time

@@ -43,6 +43,8 @@ SIGNATURES = {
     "loco_output_frames": (_i64, [_i64]),
     "loco_workspace_bytes": (_sz, [_vp, _i32, _i64]),
     "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_set_precision": (C.c_int, [_vp, C.c_int]),
+    "loco_get_precision": (C.c_int, [_vp]),
     "loco_set_taps": (C.c_int, [_vp, _vp, _vp, _vp]),
     "loco_set_profiling": (C.c_int, [_vp, C.c_int]),
     "loco_profile_reset": (C.c_int, [_vp]),
@@ -55,6 +57,9 @@ SIGNATURES = {
     "loco_op_frame_counts": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "loco_op_pos_conv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "loco_op_split_f16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "loco_op_gemm_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                                     _i32, _i32, _i64, _i64, _i64, _i64, _vp]),
     "loco_head_last_error": (C.c_char_p, []),
     "loco_head_create": (_vp, [C.c_int]),
     "loco_head_destroy": (None, [_vp]),

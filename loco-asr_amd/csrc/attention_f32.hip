@@ -36,8 +36,12 @@ constexpr int AT_LDK = kHeadDim + 4;
 constexpr int AT_KT = AT_BK * AT_LDK;    // floats per K buffer
 constexpr int AT_VT = AT_BK * kHeadDim;  // floats per V buffer
 
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ qp,
                                                            const int32_t* __restrict__ frames, float* __restrict__ ctx,
+                                                           _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
                                                            int T) {
     // two K/V buffers: tile t+1 is written while tile t is consumed -> ONE barrier per tile
     __shared__ __attribute__((aligned(16))) float kl[2 * AT_KT];
@@ -271,23 +275,43 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (iq < T) {
-        float* orow = ctx + ((long)b * T + iq) * kHidden + head * kHeadDim + 4 * h;
+        const long obase = ((long)b * T + iq) * kHidden + head * kHeadDim + 4 * h;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            float4 a, c;
-            a.x = o0[4 * g4 + 0] * inv; a.y = o0[4 * g4 + 1] * inv; a.z = o0[4 * g4 + 2] * inv; a.w = o0[4 * g4 + 3] * inv;
-            c.x = o1[4 * g4 + 0] * inv; c.y = o1[4 * g4 + 1] * inv; c.z = o1[4 * g4 + 2] * inv; c.w = o1[4 * g4 + 3] * inv;
-            *reinterpret_cast<float4*>(orow + 8 * g4) = a;
-            *reinterpret_cast<float4*>(orow + 32 + 8 * g4) = c;
+            float a[4], c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = o0[4 * g4 + e] * inv;
+                c[e] = o1[4 * g4 + e] * inv;
+            }
+            if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision out-projection GEMM
+                h4_t ah, al, ch, cl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    asm volatile("" : "+v"(a[e]), "+v"(c[e]));
+                    ah[e] = (_Float16)a[e]; al[e] = (_Float16)(a[e] - (float)ah[e]);
+                    ch[e] = (_Float16)c[e]; cl[e] = (_Float16)(c[e] - (float)ch[e]);
+                }
+                *reinterpret_cast<h4_t*>(ctx_hi + obase + 8 * g4) = ah;
+                *reinterpret_cast<h4_t*>(ctx_lo + obase + 8 * g4) = al;
+                *reinterpret_cast<h4_t*>(ctx_hi + obase + 32 + 8 * g4) = ch;
+                *reinterpret_cast<h4_t*>(ctx_lo + obase + 32 + 8 * g4) = cl;
+            } else {
+                *reinterpret_cast<float4*>(ctx + obase + 8 * g4) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<float4*>(ctx + obase + 32 + 8 * g4) = make_float4(c[0], c[1], c[2], c[3]);
+            }
         }
     }
 }
 
 hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,
-                            hipStream_t s) {
+                            hipStream_t s, void* ctx_hi, void* ctx_lo) {
     if (B <= 0 || T <= 0 || B > 65535) return hipErrorInvalidValue;
     dim3 grid((T + AT_BQ - 1) / AT_BQ, kHeads, B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, qkv, qp, frames, ctx, T);
+    if (ctx_hi)
+        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)ctx_hi, (_Float16*)ctx_lo, T);
+    else
+        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)nullptr, (_Float16*)nullptr, T);
     return hipGetLastError();
 }
 

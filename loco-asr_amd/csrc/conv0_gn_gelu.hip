@@ -99,10 +99,14 @@ __global__ __launch_bounds__(512) void conv0_gn_coeffs_kernel(const double* __re
 // The waveform window of the block sits in LDS and is read by broadcast (every lane the same address).
 constexpr int kFramesPerBlock = 64;
 
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ wav, long L, long T0,
                                                           const float* __restrict__ w, const float* __restrict__ gn_b,
                                                           const float* __restrict__ mean, const float* __restrict__ scale,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, _Float16* __restrict__ out_hi,
+                                                          _Float16* __restrict__ out_lo) {
     __shared__ float xs[kFramesPerBlock * 5 + 8];
     const int b = blockIdx.y;
     const long t0 = (long)blockIdx.x * kFramesPerBlock;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     const float be0 = gn_b[c0], be1 = gn_b[c0 + 1];
     __syncthreads();
 
-    float* o = out + ((long)b * T0 + t0) * kConvDim + c0;
+    const long obase = ((long)b * T0 + t0) * kConvDim + c0;
     for (int t = 0; t < nt; ++t) {
         float y0 = 0.f, y1 = 0.f;
 #pragma unroll
@@ -132,15 +136,23 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
             y0 = fmaf(w0[k], xv, y0);
             y1 = fmaf(w1[k], xv, y1);
         }
-        float2 r;
-        r.x = gelu_erf(fmaf(y0 - mu0, sc0, be0));
-        r.y = gelu_erf(fmaf(y1 - mu1, sc1, be1));
-        *reinterpret_cast<float2*>(o + (long)t * kConvDim) = r;
+        float r0 = gelu_erf(fmaf(y0 - mu0, sc0, be0));
+        float r1 = gelu_erf(fmaf(y1 - mu1, sc1, be1));
+        if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
+            asm volatile("" : "+v"(r0), "+v"(r1));
+            h2_t hi, lo;
+            hi[0] = (_Float16)r0; hi[1] = (_Float16)r1;
+            lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
+            *reinterpret_cast<h2_t*>(out_hi + obase + (long)t * kConvDim) = hi;
+            *reinterpret_cast<h2_t*>(out_lo + obase + (long)t * kConvDim) = lo;
+        } else {
+            *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(r0, r1);
+        }
     }
 }
 
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
-                                float* out, void* scratch, float eps, hipStream_t s) {
+                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi, void* out_lo) {
     const long T0 = conv_out_len(L, 10, 5);
     if (B <= 0 || T0 <= 0) return hipErrorInvalidValue;
     double* partial = reinterpret_cast<double*>(scratch);
@@ -150,7 +162,12 @@ hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w,
     hipLaunchKernelGGL(conv0_moments_kernel, dim3(kConv0Parts, B), dim3(256), 0, s, wav, L, T0, partial);
     hipLaunchKernelGGL(conv0_gn_coeffs_kernel, dim3(B), dim3(512), 0, s, partial, total, w, gn_w, T0, eps, mean, scale);
     const unsigned nblk = (unsigned)((T0 + kFramesPerBlock - 1) / kFramesPerBlock);
-    hipLaunchKernelGGL(conv0_apply_kernel, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out);
+    if (out_hi)
+        hipLaunchKernelGGL(conv0_apply_kernel<true>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
+                           (_Float16*)out_hi, (_Float16*)out_lo);
+    else
+        hipLaunchKernelGGL(conv0_apply_kernel<false>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
+                           (_Float16*)nullptr, (_Float16*)nullptr);
     return hipGetLastError();
 }
 

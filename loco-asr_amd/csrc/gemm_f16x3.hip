@@ -1,0 +1,241 @@
+// Split-precision GEMM: fp32-class accuracy at the fp16 matrix-core rate.
+//
+//   C = epi(A W^T + bias) with  A = A_hi + A_lo,  W = W_hi + W_lo  (each part fp16, hi = fp16(x), lo = fp16(x - hi))
+//   A W^T ~= A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T          (the dropped lo*lo term is ~2^-22 relative)
+//
+// Every partial product of two fp16 values is exact in the MFMA's fp32 accumulator, so the only errors are the
+// 22-bit hi+lo representation and the dropped term: the whole encoder lands at 2.7e-6 relative L2 of an fp64
+// evaluation, against 6.5e-7 for exact fp32 and 1.6e-3 for plain fp16 (BASELINE.md probe; emulation in DESIGN.md §8).
+// Three v_mfma_f32_32x32x16_f16 (32 cycles, 32 768 FLOP each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles,
+// 4 096 FLOP each): 5.3x fewer matrix-pipe cycles per algorithmic FLOP.
+//
+// Operands arrive ALREADY split -- weights once at load time, activations by the epilogue of the kernel that
+// produced them (same bytes as fp32: 2+2) -- so this kernel moves exactly the bytes of the fp32 GEMM and spends
+// no VALU on conversion.  Structure = gemm_f32.hip: 128x128x32 tile, 4 waves x (2x2) 32x32 sub-tiles,
+// D = W_tile * A_tile^T orientation for 16-byte epilogue accesses, global loads two k-tiles ahead, fragments
+// half a tile ahead, second half after the barrier.  LDS: four fp16 planes (A_hi, A_lo, W_hi, W_lo) of 128 rows x
+// 80 bytes (64 data + 16 pad: a 16-lane ds_read_b128 group covers all 16 sixteen-byte slots), two buffers = 80 KB,
+// two workgroups per CU.
+#include "loco_kernels.h"
+
+namespace loco {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int SBM = 128, SBN = 128, SBK = 32;
+constexpr int SLD = SBK + 8;          // halves per LDS row (80 bytes)
+constexpr int SPLANE = 128 * SLD;     // halves per plane
+constexpr int SBUF = 4 * SPLANE;      // A_hi, A_lo, W_hi, W_lo
+
+template <int EPI, bool OUT_SPLIT>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmSplitArgs p, int tiles_m, int tiles_n, int nblk) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * SBUF];
+
+    // XCD-aware bijective tile map (see gemm_f32.hip)
+    int mt, nt, z;
+    {
+        const int q = nblk >> 3, rr = nblk & 7;
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int t = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
+        nt = t % tiles_n;
+        const int rest = t / tiles_n;
+        mt = rest % tiles_m;
+        z = rest / tiles_m;
+    }
+    const int z1 = z / p.nb2, z2 = z % p.nb2;
+    const long aoff = z1 * p.sA1 + z2 * p.sA2;
+    const long coff = z1 * p.sC1 + z2 * p.sC2;
+    const int m0 = mt * SBM, n0 = nt * SBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // staging: 16-byte piece f = tid + 256*q of a 128 x 64-byte plane tile -> row f/4, piece f%4
+    const int srow = tid >> 2, sk = (tid & 3) * 8;
+    long ga[2], gw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int ra = m0 + srow + 64 * q;
+        ra = ra < p.M ? ra : p.M - 1;
+        int rw = n0 + srow + 64 * q;
+        rw = rw < p.N ? rw : p.N - 1;
+        ga[q] = aoff + (long)ra * p.lda + sk;
+        gw[q] = (long)rw * p.ldw + sk;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    h8 s0[8], s1[8];  // staging sets: [Ahi q0,q1 | Alo q0,q1 | Whi q0,q1 | Wlo q0,q1]
+#define SP_GLOAD(S, kt)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                          \
+        S[q] = *reinterpret_cast<const h8*>(p.Ahi + ga[q] + (long)(kt) * SBK);               \
+        S[2 + q] = *reinterpret_cast<const h8*>(p.Alo + ga[q] + (long)(kt) * SBK);           \
+        S[4 + q] = *reinterpret_cast<const h8*>(p.Whi + gw[q] + (long)(kt) * SBK);           \
+        S[6 + q] = *reinterpret_cast<const h8*>(p.Wlo + gw[q] + (long)(kt) * SBK);           \
+    }
+#define SP_LSTORE(S, buf)                                                                    \
+    _Pragma("unroll") for (int pl = 0; pl < 4; ++pl)                                         \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                        \
+            *reinterpret_cast<h8*>(lds + (buf) * SBUF + pl * SPLANE + (srow + 64 * q) * SLD + sk) = S[2 * pl + q];
+
+    SP_GLOAD(s0, 0)
+    SP_LSTORE(s0, 0)
+    const int nk = p.K / SBK;
+    if (nk > 1) { SP_GLOAD(s0, 1) }
+    __syncthreads();
+
+    const int fa = (wm * 64 + r) * SLD + 8 * h;
+    const int fw = (wn * 64 + r) * SLD + 8 * h;
+    // fragments of k-step ks: F[0..1] = A_hi rows {0,32}, F[2..3] = A_lo, F[4..5] = W_hi, F[6..7] = W_lo
+#define SP_FRAGS(buf, ks, F)                                                                                     \
+    {                                                                                                            \
+        const _Float16* b_ = lds + (buf) * SBUF + 16 * (ks);                                                     \
+        F[0] = *reinterpret_cast<const h8*>(b_ + fa);                                                            \
+        F[1] = *reinterpret_cast<const h8*>(b_ + fa + 32 * SLD);                                                 \
+        F[2] = *reinterpret_cast<const h8*>(b_ + SPLANE + fa);                                                   \
+        F[3] = *reinterpret_cast<const h8*>(b_ + SPLANE + fa + 32 * SLD);                                        \
+        F[4] = *reinterpret_cast<const h8*>(b_ + 2 * SPLANE + fw);                                               \
+        F[5] = *reinterpret_cast<const h8*>(b_ + 2 * SPLANE + fw + 32 * SLD);                                    \
+        F[6] = *reinterpret_cast<const h8*>(b_ + 3 * SPLANE + fw);                                               \
+        F[7] = *reinterpret_cast<const h8*>(b_ + 3 * SPLANE + fw + 32 * SLD);                                    \
+    }
+    // 12 MFMAs: small terms first, then hi*hi
+#define SP_MFMA(F)                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[6 + j], F[i], acc[i][j], 0, 0, 0);              \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[2 + i], acc[i][j], 0, 0, 0);          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[i], acc[i][j], 0, 0, 0);              \
+        }
+
+    int cur = 0;
+    h8 fx[8], fy[8];
+    SP_FRAGS(0, 0, fx)
+#define SP_KTILE(SCUR, SNEXT)                                         \
+    {                                                                 \
+        const bool more = kt + 1 < nk;                                \
+        if (kt + 2 < nk) { SP_GLOAD(SNEXT, kt + 2) }                  \
+        SP_FRAGS(cur, 1, fy)                                          \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        SP_MFMA(fx)                                                   \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        if (more) { SP_LSTORE(SCUR, cur ^ 1) }                        \
+        __syncthreads();                                              \
+        cur ^= 1;                                                     \
+        if (more) { SP_FRAGS(cur, 0, fx) }                            \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        SP_MFMA(fy)                                                   \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        SP_KTILE(s0, s1)
+        ++kt;
+        SP_KTILE(s1, s0)
+        --kt;
+    }
+    if (kt < nk) SP_KTILE(s0, s1)
+#undef SP_KTILE
+#undef SP_MFMA
+#undef SP_FRAGS
+#undef SP_LSTORE
+#undef SP_GLOAD
+
+    // epilogue: acc[i][j][e] = C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]
+    const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 64 + i * 32 + r;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
+                if (n < p.N) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    if (EPI == kEpiGelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
+                    const long o = coff + (long)m * p.ldc + n;
+                    if (OUT_SPLIT) {
+                        h4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            // Pin v as a rounded fp32 value first: with fp contraction hipcc folds the producing multiply
+                            // into v_fma_mix*_f16 for the lo term but converts the stored hi from the fp32-rounded
+                            // product -- a double-rounding mismatch worth one fp16 ulp of hi on ties.
+                            asm volatile("" : "+v"(v[e]));
+                            hi[e] = (_Float16)v[e];
+                            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+                        }
+                        *reinterpret_cast<h4*>(p.Chi + o) = hi;
+                        *reinterpret_cast<h4*>(p.Clo + o) = lo;
+                    } else {
+                        *reinterpret_cast<f32x4*>(p.C + o) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % SBK != 0) return hipErrorInvalidValue;
+    if ((a.lda | a.ldw | a.sA1 | a.sA2) & 7) return hipErrorInvalidValue;  // 16-byte staging of 8 halves
+    if ((a.N | a.ldc | a.sC1 | a.sC2) & 3) return hipErrorInvalidValue;
+    if (a.epilogue == kEpiResidual && (!a.R || (a.ldr & 3))) return hipErrorInvalidValue;
+    const bool split = a.Chi != nullptr;
+    if (split ? (a.Clo == nullptr) : (a.C == nullptr)) return hipErrorInvalidValue;
+    const int tiles_m = (a.M + SBM - 1) / SBM, tiles_n = (a.N + SBN - 1) / SBN;
+    const long nblk = (long)tiles_m * tiles_n * a.nb1 * a.nb2;
+    if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk), block(256);
+#define SP_LAUNCH(EPI)                                                                                                   \
+    if (split) hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, true>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);    \
+    else hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, false>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+    switch (a.epilogue) {
+        case kEpiNone: SP_LAUNCH(kEpiNone) break;
+        case kEpiGelu: SP_LAUNCH(kEpiGelu) break;
+        case kEpiResidual: SP_LAUNCH(kEpiResidual) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef SP_LAUNCH
+    return hipGetLastError();
+}
+
+// x -> (hi, lo) fp16 planes, n % 4 == 0
+__global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        h4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = (_Float16)v[e];
+            b[e] = (_Float16)(v[e] - (float)a[e]);
+        }
+        reinterpret_cast<h4*>(hi)[i] = a;
+        reinterpret_cast<h4*>(lo)[i] = b;
+    }
+}
+
+hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s) {
+    if (n <= 0 || (n & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, n / 4);
+    return hipGetLastError();
+}
+
+}  // namespace loco

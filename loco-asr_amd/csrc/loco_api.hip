@@ -55,14 +55,20 @@ struct Tensor {
 const int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 const int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
 
+struct SplitW {  // fp16 hi/lo planes of one GEMM weight (precision mode f16x3)
+    _Float16* hi = nullptr;
+    _Float16* lo = nullptr;
+};
+
 struct LayerW {
     float* wqkv = nullptr;  // [2304,768], q rows pre-scaled by 1/8
     float* bqkv = nullptr;  // [2304]
+    SplitW sqkv, so, s1, s2;
 };
 
-enum KernelId { K_GEMM = 0, K_ATTN, K_LN, K_CONV0, K_POSCONV, K_FRAMES, K_COPY, K_COUNT };
+enum KernelId { K_GEMM = 0, K_ATTN, K_LN, K_CONV0, K_POSCONV, K_FRAMES, K_COPY, K_GEMM_SPLIT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"gemm_f32",     "attention_f32", "layernorm", "conv0_gn_gelu",
-                                           "pos_conv_f32", "frame_counts",  "copy"};
+                                           "pos_conv_f32", "frame_counts",  "copy",      "gemm_f16x3"};
 
 struct ProfRec {
     hipEvent_t a, b;
@@ -81,6 +87,9 @@ struct loco_encoder {
     // prepared
     float* conv_w[7] = {nullptr};  // [512, k*512] tap-major (layer 0 stays [512,10])
     float* pos_w = nullptr;        // [16][128][48][48]
+    SplitW conv_s[7];              // split copies of conv_w[1..6]
+    SplitW proj_s;                 // feature projection
+    int precision = 0;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA for the GEMMs
     std::vector<LayerW> layers;
     float* sin_tab = nullptr;
     int sin_rows = 0;
@@ -155,7 +164,7 @@ struct Plan {
     long L;
     long Tc[7];  // conv output lengths
     long T, M;
-    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, total;
+    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1, total;
 };
 
 bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
@@ -187,6 +196,8 @@ bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     p.off_qkv = take((size_t)p.M * kQkv * f);
     p.off_qp = take((size_t)p.M * kHeads * kRelN * f);
     p.off_ffn = take((size_t)p.M * e->cfg.ffn * f);
+    p.off_xs0 = take((size_t)p.M * kHidden * f);  // fp16 hi|lo planes of x0 / x1 (precision f16x3)
+    p.off_xs1 = take((size_t)p.M * kHidden * f);
     p.total = o;
     return true;
 }
@@ -226,9 +237,30 @@ int run_gemm(loco_encoder* e, hipStream_t s, const float* A, long lda, const flo
     return LOCO_OK;
 }
 
-int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const float* b, float* y, long rows, int dim) {
-    Bracket br(e, s, K_LN, 8.0 * rows * dim, 8.0 * rows * dim);
-    HIP_TRY(launch_layernorm(x, g, b, y, rows, dim, e->cfg.ln_eps, s));
+int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const float* b, float* y, long rows, int dim,
+           _Float16* yhi = nullptr, _Float16* ylo = nullptr) {
+    Bracket br(e, s, K_LN, 8.0 * rows * dim, (y && yhi ? 12.0 : 8.0) * rows * dim);
+    HIP_TRY(launch_layernorm(x, g, b, y, rows, dim, e->cfg.ln_eps, s, yhi, ylo));
+    return LOCO_OK;
+}
+
+// split-precision GEMM: A and W as fp16 hi/lo planes; output fp32 (C) or planes (Chi/Clo)
+int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
+                   const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
+                   int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0) {
+    GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, 1, sA1, 0, sC1, 0, epi};
+    const double nb = nb1;
+    const double flops = 2.0 * M * (double)N * K * nb;
+    const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
+    Bracket br(e, s, K_GEMM_SPLIT, flops, bytes);
+    HIP_TRY(launch_gemm_split(a, s));
+    return LOCO_OK;
+}
+
+int make_split(SplitW& w, const float* src, size_t n, hipStream_t s) {
+    if (!w.hi) HIP_TRY(hipMalloc(&w.hi, n * sizeof(_Float16)));
+    if (!w.lo) HIP_TRY(hipMalloc(&w.lo, n * sizeof(_Float16)));
+    HIP_TRY(launch_split_f16(src, w.hi, w.lo, (long)n, s));
     return LOCO_OK;
 }
 
@@ -256,6 +288,219 @@ int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s) {
     e->sin_tab = nt;
     e->sin_rows = want;
     e->sin_user = false;
+    return LOCO_OK;
+}
+
+
+struct Bufs {
+    int32_t* frames;
+    const int32_t* frames_or_null;
+    float *bufA, *bufB, *x0, *x1, *tmp, *ctx, *qkv, *qp, *ffn;
+    _Float16 *xs0, *xs1;
+    char* c0scratch;
+};
+
+// ---- precision 0: every contraction on the exact-fp32 MFMA ------------------------------------------------------
+int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
+                hipStream_t s) {
+    const int B = p.B;
+    const long L = p.L;
+    const int T = (int)p.T;
+    const long M = p.M;
+    int rc;
+    float *bufA = bf.bufA, *bufB = bf.bufB, *x0 = bf.x0, *x1 = bf.x1, *tmp = bf.tmp, *ctx = bf.ctx, *qkv = bf.qkv, *qp = bf.qp,
+          *ffn = bf.ffn;
+    const int32_t* frames_or_null = bf.frames_or_null;
+    const std::string pn = "prenet.", we = "wrapped_encoder.";
+    // ---- feature encoder (HF :484-494)
+    {
+        const double outb = 4.0 * B * (double)p.Tc[0] * kConvDim;
+        Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
+        HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
+                                     W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), bufA,
+                                     bf.c0scratch, e->cfg.ln_eps, s));
+    }
+    float* cin = bufA;
+    float* cout = bufB;
+    for (int i = 1; i < 7; ++i) {
+        const long Tin = p.Tc[i - 1], Tout = p.Tc[i];
+        rc = run_gemm(e, s, cin, (long)kConvS[i] * kConvDim, e->conv_w[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
+                      cout, kConvDim, (int)Tout, kConvDim, kConvK[i] * kConvDim, kEpiGelu, B, 1, Tin * kConvDim, 0,
+                      Tout * kConvDim, 0);
+        if (rc) return rc;
+        float* t = cin;
+        cin = cout;
+        cout = t;
+    }
+    float* feats = cin;  // [M,512]
+    if (e->tap_conv && (rc = run_copy(e, s, e->tap_conv, feats, (size_t)M * kConvDim))) return rc;
+
+    // ---- feature projection (HF :498-510): LayerNorm(512) in place, then Linear(512,768)
+    if ((rc = run_ln(e, s, feats, W(e, pn + "feature_projection.layer_norm.weight"),
+                     W(e, pn + "feature_projection.layer_norm.bias"), feats, M, kConvDim)))
+        return rc;
+    if ((rc = run_gemm(e, s, feats, kConvDim, W(e, pn + "feature_projection.projection.weight"), kConvDim,
+                       W(e, pn + "feature_projection.projection.bias"), nullptr, 0, x1, kHidden, (int)M, kHidden, kConvDim,
+                       kEpiNone)))
+        return rc;
+    if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
+
+    // ---- positional conv + sinusoid (HF :555-564)
+    {
+        Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
+        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
+    }
+    if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
+
+    // ---- encoder (HF :1276-1304)
+    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden))) return rc;
+    const float* pe_k = W(e, we + "embed_positions.pe_k.weight");
+    const int nl = e->cfg.layers;
+    for (int l = 0; l < nl; ++l) {
+        if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
+        const std::string b = we + "layers." + std::to_string(l) + ".";
+        const LayerW& lw = e->layers[l];
+        // fused q|k|v projection, q pre-scaled (HF :891,911-914)
+        if ((rc = run_gemm(e, s, x0, kHidden, lw.wqkv, kHidden, lw.bqkv, nullptr, 0, qkv, kQkv, (int)M, kQkv, kHidden, kEpiNone)))
+            return rc;
+        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T  -> [B,12,T,320]
+        if ((rc = run_gemm(e, s, qkv, kQkv, pe_k, kHeadDim, nullptr, nullptr, 0, qp, kRelN, T, kRelN, kHeadDim, kEpiNone, B,
+                           kHeads, (long)T * kQkv, kHeadDim, (long)kHeads * T * kRelN, (long)T * kRelN)))
+            return rc;
+        {
+            const double tt = (double)T * T;
+            Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
+            HIP_TRY(launch_attention(qkv, qp, frames_or_null, ctx, B, T, s));
+        }
+        // out_proj + residual (HF :984,1056), LayerNorm (HF :1058)
+        if ((rc = run_gemm(e, s, ctx, kHidden, W(e, b + "attention.out_proj.weight"), kHidden, W(e, b + "attention.out_proj.bias"),
+                           x0, kHidden, tmp, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
+            return rc;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), x1, M, kHidden))) return rc;
+        // FFN (HF :1003-1010) + residual + final LayerNorm (HF :1059-1060)
+        if ((rc = run_gemm(e, s, x1, kHidden, W(e, b + "feed_forward.intermediate_dense.weight"), kHidden,
+                           W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0, ffn, e->cfg.ffn, (int)M, e->cfg.ffn,
+                           kHidden, kEpiGelu)))
+            return rc;
+        if ((rc = run_gemm(e, s, ffn, e->cfg.ffn, W(e, b + "feed_forward.output_dense.weight"), e->cfg.ffn,
+                           W(e, b + "feed_forward.output_dense.bias"), x1, kHidden, tmp, kHidden, (int)M, kHidden, e->cfg.ffn,
+                           kEpiResidual)))
+            return rc;
+        float* dst = (l == nl - 1) ? out : x0;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"), dst, M, kHidden)))
+            return rc;
+    }
+    if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
+    if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
+    return LOCO_OK;
+}
+
+// ---- precision 1: the GEMMs (conv layers 1-6, feature projection, QKV / out / FFN projections = 90 % of the FLOPs) on the
+// fp16 x3 split MFMA; every producer writes the fp16 hi/lo planes its consumer needs, so no separate conversion pass
+// exists.  conv0, the positional conv, the Qp table and attention stay on their fp32 kernels; residuals, LayerNorm
+// statistics and softmax stay fp32.
+int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
+                  hipStream_t s) {
+    const int B = p.B;
+    const long L = p.L;
+    const int T = (int)p.T;
+    const long M = p.M;
+    int rc;
+    float *x0 = bf.x0, *x1 = bf.x1, *tmp = bf.tmp, *qkv = bf.qkv, *qp = bf.qp;
+    const int32_t* frames_or_null = bf.frames_or_null;
+    const std::string pn = "prenet.", we = "wrapped_encoder.";
+    // a fp32 buffer of n elements holds the two fp16 planes of n elements back to back
+    auto planes = [](float* base, size_t n, _Float16*& hi, _Float16*& lo) {
+        hi = reinterpret_cast<_Float16*>(base);
+        lo = hi + n;
+    };
+
+    // ---- feature encoder: conv0 writes planes, conv1-5 planes -> planes, conv6 planes -> fp32 (LayerNorm input)
+    _Float16 *ihi, *ilo, *ohi, *olo;
+    planes(bf.bufA, (size_t)B * p.Tc[0] * kConvDim, ihi, ilo);
+    {
+        const double outb = 4.0 * B * (double)p.Tc[0] * kConvDim;
+        Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
+        HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
+                                     W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), nullptr, bf.c0scratch,
+                                     e->cfg.ln_eps, s, ihi, ilo));
+    }
+    float* cin = bf.bufA;
+    float* cout = bf.bufB;
+    for (int i = 1; i < 7; ++i) {
+        const long Tin = p.Tc[i - 1], Tout = p.Tc[i];
+        planes(cin, (size_t)B * Tin * kConvDim, ihi, ilo);
+        planes(cout, (size_t)B * Tout * kConvDim, ohi, olo);
+        const bool last = i == 6;
+        rc = run_gemm_split(e, s, ihi, ilo, (long)kConvS[i] * kConvDim, e->conv_s[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
+                            last ? cout : nullptr, last ? nullptr : ohi, last ? nullptr : olo, kConvDim, (int)Tout, kConvDim,
+                            kConvK[i] * kConvDim, kEpiGelu, B, Tin * kConvDim, Tout * kConvDim);
+        if (rc) return rc;
+        float* t = cin;
+        cin = cout;
+        cout = t;
+    }
+    float* feats = cin;  // [M,512] fp32
+    if (e->tap_conv && (rc = run_copy(e, s, e->tap_conv, feats, (size_t)M * kConvDim))) return rc;
+
+    // ---- feature projection: LayerNorm(512) -> planes (in the idle conv buffer) -> Linear(512,768) -> x1 fp32
+    planes(cout, (size_t)M * kConvDim, ohi, olo);
+    if ((rc = run_ln(e, s, feats, W(e, pn + "feature_projection.layer_norm.weight"), W(e, pn + "feature_projection.layer_norm.bias"),
+                     nullptr, M, kConvDim, ohi, olo)))
+        return rc;
+    if ((rc = run_gemm_split(e, s, ohi, olo, kConvDim, e->proj_s, kConvDim, W(e, pn + "feature_projection.projection.bias"), nullptr, 0,
+                             x1, nullptr, nullptr, kHidden, (int)M, kHidden, kConvDim, kEpiNone)))
+        return rc;
+    if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
+
+    // ---- positional conv + sinusoid (fp32 MFMA kernel)
+    {
+        Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
+        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
+    }
+    if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
+
+    // ---- encoder
+    _Float16 *x0hi = bf.xs0, *x0lo = bf.xs0 + (size_t)M * kHidden;
+    _Float16 *x1hi = bf.xs1, *x1lo = bf.xs1 + (size_t)M * kHidden;
+    _Float16 *chi, *clo, *fhi, *flo;
+    planes(bf.ctx, (size_t)M * kHidden, chi, clo);
+    planes(bf.ffn, (size_t)M * e->cfg.ffn, fhi, flo);
+    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden, x0hi, x0lo))) return rc;
+    const float* pe_k = W(e, we + "embed_positions.pe_k.weight");
+    const int nl = e->cfg.layers;
+    for (int l = 0; l < nl; ++l) {
+        if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
+        const std::string b = we + "layers." + std::to_string(l) + ".";
+        const LayerW& lw = e->layers[l];
+        if ((rc = run_gemm_split(e, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, qkv, nullptr, nullptr, kQkv, (int)M,
+                                 kQkv, kHidden, kEpiNone)))
+            return rc;
+        if ((rc = run_gemm(e, s, qkv, kQkv, pe_k, kHeadDim, nullptr, nullptr, 0, qp, kRelN, T, kRelN, kHeadDim, kEpiNone, B, kHeads,
+                           (long)T * kQkv, kHeadDim, (long)kHeads * T * kRelN, (long)T * kRelN)))
+            return rc;
+        {
+            const double tt = (double)T * T;
+            Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
+            HIP_TRY(launch_attention(qkv, qp, frames_or_null, nullptr, B, T, s, chi, clo));
+        }
+        if ((rc = run_gemm_split(e, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), x0, kHidden, tmp, nullptr,
+                                 nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
+            return rc;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), x1, M, kHidden, x1hi, x1lo))) return rc;
+        if ((rc = run_gemm_split(e, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
+                                 nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu)))
+            return rc;
+        if ((rc = run_gemm_split(e, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), x1, kHidden,
+                                 tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual)))
+            return rc;
+        const bool last = l == nl - 1;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"), last ? out : x0, M, kHidden,
+                         last ? nullptr : x0hi, last ? nullptr : x0lo)))
+            return rc;
+    }
+    if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
+    if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
     return LOCO_OK;
 }
 
@@ -319,9 +564,19 @@ void loco_destroy(loco_encoder* e) {
     for (auto& kv : e->raw) (void)hipFree(kv.second.d);
     for (int i = 1; i < 7; ++i) (void)hipFree(e->conv_w[i]);
     (void)hipFree(e->pos_w);
+    auto free_split = [](SplitW& w) {
+        (void)hipFree(w.hi);
+        (void)hipFree(w.lo);
+    };
+    for (int i = 1; i < 7; ++i) free_split(e->conv_s[i]);
+    free_split(e->proj_s);
     for (auto& l : e->layers) {
         (void)hipFree(l.wqkv);
         (void)hipFree(l.bqkv);
+        free_split(l.sqkv);
+        free_split(l.so);
+        free_split(l.s1);
+        free_split(l.s2);
     }
     (void)hipFree(e->sin_tab);
     for (auto& r : e->recs) {
@@ -413,7 +668,21 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
         HIP_TRY(launch_scale_copy(W(e, b + "k_proj.bias"), lw.bqkv + kHidden, kHidden, 1.0f, s));
         HIP_TRY(launch_scale_copy(W(e, b + "v_proj.bias"), lw.bqkv + 2 * kHidden, kHidden, 1.0f, s));
     }
-    int rc = ensure_sin_rows(e, 4002, s);
+    // fp16 hi/lo planes of every GEMM weight for precision mode f16x3 (378 MB; built unconditionally so that the
+    // mode can be switched per forward)
+    int rc = LOCO_OK;
+    for (int i = 1; i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
+    if (!rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
+    for (int l = 0; l < e->cfg.layers && !rc; ++l) {
+        LayerW& lw = e->layers[l];
+        const std::string b = w + "layers." + std::to_string(l) + ".";
+        rc = make_split(lw.sqkv, lw.wqkv, 3 * hh, s);
+        if (!rc) rc = make_split(lw.so, W(e, b + "attention.out_proj.weight"), hh, s);
+        if (!rc) rc = make_split(lw.s1, W(e, b + "feed_forward.intermediate_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
+        if (!rc) rc = make_split(lw.s2, W(e, b + "feed_forward.output_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
+    }
+    if (rc) return rc;
+    rc = ensure_sin_rows(e, 4002, s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     e->finalized = true;
@@ -433,6 +702,14 @@ size_t loco_workspace_bytes(const loco_encoder* e, int32_t B, int64_t L) {
     if (!e || !make_plan(e, B, L, p)) return 0;
     return p.total;
 }
+
+int loco_set_precision(loco_encoder* e, int mode) {
+    if (!e || (mode != 0 && mode != 1)) return fail(LOCO_E_INVALID, "loco_set_precision: mode must be 0 (f32) or 1 (f16x3)");
+    e->precision = mode;
+    return LOCO_OK;
+}
+
+int loco_get_precision(const loco_encoder* e) { return e ? e->precision : LOCO_E_INVALID; }
 
 int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection, float* prenet) {
     if (!e) return fail(LOCO_E_INVALID, "null encoder");
@@ -470,9 +747,6 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     float* qkv = reinterpret_cast<float*>(ws + p.off_qkv);
     float* qp = reinterpret_cast<float*>(ws + p.off_qp);
     float* ffn = reinterpret_cast<float*>(ws + p.off_ffn);
-    const std::string pn = "prenet.", we = "wrapped_encoder.";
-    const int T = (int)p.T;
-    const long M = p.M;
 
     // ---- valid frame counts (HF :569-598)
     {
@@ -481,87 +755,9 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     }
     const int32_t* frames_or_null = mask ? frames : nullptr;
 
-    // ---- feature encoder (HF :484-494)
-    {
-        const double outb = 4.0 * B * (double)p.Tc[0] * kConvDim;
-        Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
-        HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
-                                     W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), bufA,
-                                     ws + p.off_c0scratch, e->cfg.ln_eps, s));
-    }
-    float* cin = bufA;
-    float* cout = bufB;
-    for (int i = 1; i < 7; ++i) {
-        const long Tin = p.Tc[i - 1], Tout = p.Tc[i];
-        rc = run_gemm(e, s, cin, (long)kConvS[i] * kConvDim, e->conv_w[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
-                      cout, kConvDim, (int)Tout, kConvDim, kConvK[i] * kConvDim, kEpiGelu, B, 1, Tin * kConvDim, 0,
-                      Tout * kConvDim, 0);
-        if (rc) return rc;
-        float* t = cin;
-        cin = cout;
-        cout = t;
-    }
-    float* feats = cin;  // [M,512]
-    if (e->tap_conv && (rc = run_copy(e, s, e->tap_conv, feats, (size_t)M * kConvDim))) return rc;
-
-    // ---- feature projection (HF :498-510): LayerNorm(512) in place, then Linear(512,768)
-    if ((rc = run_ln(e, s, feats, W(e, pn + "feature_projection.layer_norm.weight"),
-                     W(e, pn + "feature_projection.layer_norm.bias"), feats, M, kConvDim)))
-        return rc;
-    if ((rc = run_gemm(e, s, feats, kConvDim, W(e, pn + "feature_projection.projection.weight"), kConvDim,
-                       W(e, pn + "feature_projection.projection.bias"), nullptr, 0, x1, kHidden, (int)M, kHidden, kConvDim,
-                       kEpiNone)))
-        return rc;
-    if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
-
-    // ---- positional conv + sinusoid (HF :555-564)
-    {
-        Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
-        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
-    }
-    if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
-
-    // ---- encoder (HF :1276-1304)
-    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden))) return rc;
-    const float* pe_k = W(e, we + "embed_positions.pe_k.weight");
-    const int nl = e->cfg.layers;
-    for (int l = 0; l < nl; ++l) {
-        if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
-        const std::string b = we + "layers." + std::to_string(l) + ".";
-        const LayerW& lw = e->layers[l];
-        // fused q|k|v projection, q pre-scaled (HF :891,911-914)
-        if ((rc = run_gemm(e, s, x0, kHidden, lw.wqkv, kHidden, lw.bqkv, nullptr, 0, qkv, kQkv, (int)M, kQkv, kHidden, kEpiNone)))
-            return rc;
-        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T  -> [B,12,T,320]
-        if ((rc = run_gemm(e, s, qkv, kQkv, pe_k, kHeadDim, nullptr, nullptr, 0, qp, kRelN, T, kRelN, kHeadDim, kEpiNone, B,
-                           kHeads, (long)T * kQkv, kHeadDim, (long)kHeads * T * kRelN, (long)T * kRelN)))
-            return rc;
-        {
-            const double tt = (double)T * T;
-            Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
-            HIP_TRY(launch_attention(qkv, qp, frames_or_null, ctx, B, T, s));
-        }
-        // out_proj + residual (HF :984,1056), LayerNorm (HF :1058)
-        if ((rc = run_gemm(e, s, ctx, kHidden, W(e, b + "attention.out_proj.weight"), kHidden, W(e, b + "attention.out_proj.bias"),
-                           x0, kHidden, tmp, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
-            return rc;
-        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), x1, M, kHidden))) return rc;
-        // FFN (HF :1003-1010) + residual + final LayerNorm (HF :1059-1060)
-        if ((rc = run_gemm(e, s, x1, kHidden, W(e, b + "feed_forward.intermediate_dense.weight"), kHidden,
-                           W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0, ffn, e->cfg.ffn, (int)M, e->cfg.ffn,
-                           kHidden, kEpiGelu)))
-            return rc;
-        if ((rc = run_gemm(e, s, ffn, e->cfg.ffn, W(e, b + "feed_forward.output_dense.weight"), e->cfg.ffn,
-                           W(e, b + "feed_forward.output_dense.bias"), x1, kHidden, tmp, kHidden, (int)M, kHidden, e->cfg.ffn,
-                           kEpiResidual)))
-            return rc;
-        float* dst = (l == nl - 1) ? out : x0;
-        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"), dst, M, kHidden)))
-            return rc;
-    }
-    if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
-    if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
-    return LOCO_OK;
+    struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
+                     reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    return e->precision == 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------
@@ -648,6 +844,24 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
                      float* out, int32_t B, int32_t T, void* stream) {
     if (!h || !w_folded || !bias || !sin_table || !out) return fail(LOCO_E_INVALID, "loco_op_pos_conv: null argument");
     HIP_TRY(launch_pos_conv(h, w_folded, bias, sin_table, frames, out, B, T, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_split_f16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
+    if (!x || !hi || !lo || n <= 0 || (n & 3)) return fail(LOCO_E_INVALID, "loco_op_split_f16: invalid argument");
+    HIP_TRY(launch_split_f16(x, hi, lo, n, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
+                       const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc, int32_t M,
+                       int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2, int64_t sA1, int64_t sA2, int64_t sC1,
+                       int64_t sC2, void* stream) {
+    if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Chi)) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3: null argument");
+    if (K % 32 || (lda | ldw) & 7) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3: K %% 32 and lda/ldw %% 8 must be 0");
+    GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, bias, R, C,
+                    (_Float16*)Chi, (_Float16*)Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epilogue};
+    HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
     return LOCO_OK;
 }
 

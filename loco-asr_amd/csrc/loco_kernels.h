@@ -36,23 +36,44 @@ struct GemmArgs {
     int epilogue;
 };
 
+// split-precision GEMM operands: fp16 hi/lo planes with the strides of the fp32 tensor they stand for
+struct GemmSplitArgs {
+    const _Float16* Ahi;
+    const _Float16* Alo;
+    const _Float16* Whi;
+    const _Float16* Wlo;
+    const float* bias;  // may be null
+    const float* R;     // fp32 residual (kEpiResidual)
+    float* C;           // fp32 output, or null when Chi/Clo are given
+    _Float16* Chi;      // split output (the next GEMM's A operand), or null
+    _Float16* Clo;
+    int M, N, K;
+    long lda, ldw, ldc, ldr;
+    int nb1, nb2;
+    long sA1, sA2, sC1, sC2;
+    int epilogue;
+};
+hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
+hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s);
+
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
-                            hipStream_t s);
+                            hipStream_t s, void* yhi = nullptr, void* ylo = nullptr);
 
 constexpr int kConv0Parts = 64;    // partial-moment blocks per clip
 constexpr int kConv0Moments = 65;  // 10 first + 55 second moments
 size_t conv0_scratch_bytes(int B);
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
-                                float* out, void* scratch, float eps, hipStream_t s);
+                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi = nullptr,
+                                void* out_lo = nullptr);
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
 hipError_t launch_pos_conv(const float* h, const float* wf, const float* bias, const float* sin_table,
                            const int32_t* frames, float* out, int B, int T, hipStream_t s);
 hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,
-                            hipStream_t s);
+                            hipStream_t s, void* ctx_hi = nullptr, void* ctx_lo = nullptr);
 
 // weight preparation (run once in loco_finalize_weights)
 hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C, int k, hipStream_t s);  // [N,C,k]->[N,k*C]

@@ -12,9 +12,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // y = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance, two-pass over registers
 // (HF nn.LayerNorm sites: modeling_speecht5.py:501,1023,1025,1276).  NV4 = dim / 256.
-template <int NV4>
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+// SPLIT: additionally (or instead, when y == nullptr) write the result as fp16 hi/lo planes -- the A operand of the
+// split-precision GEMM that consumes it (gemm_f16x3.hip).
+template <int NV4, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ b, float* __restrict__ y, long rows,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        _Float16* __restrict__ yhi, _Float16* __restrict__ ylo, long rows,
                                                         float eps) {
     constexpr int D = NV4 * 256;
     const int lane = threadIdx.x & 63;
@@ -36,28 +41,44 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
-    float4* yr = reinterpret_cast<float4*>(y + row * D);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const float4 gg = reinterpret_cast<const float4*>(g)[lane + 64 * i];
         const float4 bb = reinterpret_cast<const float4*>(b)[lane + 64 * i];
-        float4 o;
-        o.x = v[i].x * rstd * gg.x + bb.x;
-        o.y = v[i].y * rstd * gg.y + bb.y;
-        o.z = v[i].z * rstd * gg.z + bb.z;
-        o.w = v[i].w * rstd * gg.w + bb.w;
-        yr[lane + 64 * i] = o;
+        float o[4];
+        o[0] = v[i].x * rstd * gg.x + bb.x;
+        o[1] = v[i].y * rstd * gg.y + bb.y;
+        o[2] = v[i].z * rstd * gg.z + bb.z;
+        o[3] = v[i].w * rstd * gg.w + bb.w;
+        if (y) reinterpret_cast<float4*>(y + row * D)[lane + 64 * i] = make_float4(o[0], o[1], o[2], o[3]);
+        if (SPLIT) {
+            h4_t hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("" : "+v"(o[e]));  // one fp32 rounding before the split (see gemm_f16x3.hip epilogue)
+                hi[e] = (_Float16)o[e];
+                lo[e] = (_Float16)(o[e] - (float)hi[e]);
+            }
+            reinterpret_cast<h4_t*>(yhi + row * D)[lane + 64 * i] = hi;
+            reinterpret_cast<h4_t*>(ylo + row * D)[lane + 64 * i] = lo;
+        }
     }
 }
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
-                            hipStream_t s) {
-    if (rows <= 0) return hipErrorInvalidValue;
+                            hipStream_t s, void* yhi, void* ylo) {
+    if (rows <= 0 || (!y && !yhi) || ((yhi == nullptr) != (ylo == nullptr))) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((rows + 3) / 4);
-    if (dim == 768)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, s, x, g, b, y, rows, eps);
+    _Float16* hi = (_Float16*)yhi;
+    _Float16* lo = (_Float16*)ylo;
+    if (dim == 768 && !hi)
+        hipLaunchKernelGGL((layernorm_kernel<3, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+    else if (dim == 768)
+        hipLaunchKernelGGL((layernorm_kernel<3, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+    else if (dim == 512 && !hi)
+        hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
     else if (dim == 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, x, g, b, y, rows, eps);
+        hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

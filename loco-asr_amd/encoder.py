@@ -164,8 +164,13 @@ class _Ref:
 class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
     """Drop-in for ``SpeechT5ForSpeechToText(...).speecht5.encoder`` (HF modeling_speecht5.py:1325-1358)."""
 
-    def __init__(self, layers: int = LAYERS):
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def __init__(self, layers: int = LAYERS, precision: str = "f32"):
         super().__init__()
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self.precision = precision
         self._lib = _lib.load()  # raises when the HIP library is missing: no fallback
         ref = _Ref()
         self.prenet = SpeechT5SpeechEncoderPrenetMI355X(ref)
@@ -284,6 +289,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
         with torch.cuda.device(device):
             self._sync_weights(device, T + 2)
+            _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
             need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
             if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
                 self._workspace = None
@@ -329,15 +335,15 @@ class _SpeechT5Core(nn.Module):
 class SpeechT5ForSpeechToTextMI355X(nn.Module):
     """Only as much of HF's SpeechT5ForSpeechToText as the reference touches: ``.speecht5.encoder``."""
 
-    def __init__(self, layers: int = LAYERS):
+    def __init__(self, layers: int = LAYERS, precision: str = "f32"):
         super().__init__()
-        self.speecht5 = _SpeechT5Core(SpeechT5EncoderWithSpeechPrenetMI355X(layers))
+        self.speecht5 = _SpeechT5Core(SpeechT5EncoderWithSpeechPrenetMI355X(layers, precision))
         self.eval()
 
     @classmethod
-    def from_state_dicts(cls, prenet_state_dict, encoder_state_dict, layers: int = LAYERS):
+    def from_state_dicts(cls, prenet_state_dict, encoder_state_dict, layers: int = LAYERS, precision: str = "f32"):
         """What the base script does after from_pretrained (…base…py:98-100), minus the hub download."""
-        model = cls(layers)
+        model = cls(layers, precision)
         model.speecht5.encoder.wrapped_encoder.load_state_dict(encoder_state_dict)
         model.speecht5.encoder.prenet.load_state_dict(prenet_state_dict)
         return model

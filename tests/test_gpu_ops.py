@@ -223,3 +223,46 @@ def test_attention_forces_online_softmax_rescale(oracle):
     check(lib().loco_op_attention(ptr(qkvd), ptr(qpd), None, ptr(ctx), B, T, stream()))
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None).transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 3e-6
+
+
+def split16(x):
+    xd = dev(x)
+    hi = torch.empty(xd.shape, dtype=torch.float16, device="cuda")
+    lo = torch.empty_like(hi)
+    check(lib().loco_op_split_f16(ptr(xd), ptr(hi), ptr(lo), xd.numel(), stream()))
+    return hi, lo
+
+
+def test_split_f16_reconstructs_22_bits():
+    x = hu("sp.x", (4, 1000), 3.0)
+    hi, lo = split16(x)
+    assert torch.equal(hi.cpu(), x.half())
+    rec = hi.float().cpu() + lo.float().cpu()
+    assert float(((rec - x).abs() / x.abs().clamp_min(1e-3)).max()) < 2.0 ** -20
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1, 768, 768), (300, 320, 64), (1499, 2304, 768), (257, 768, 3072)])
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("out_split", [False, True])
+def test_gemm_f16x3(M, N, K, epi, out_split):
+    """split-precision GEMM vs fp64: fp32-class accuracy (bar 5e-6; exact fp32 MFMA gives ~2e-7, plain fp16 ~3e-4)."""
+    A = hu("g3.a", (M, K), 2.0)
+    W = hu("g3.w", (N, K), 2.0 / math.sqrt(K))
+    b = hu("g3.b", (N,))
+    R = hu("g3.r", (M, N))
+    ahi, alo = split16(A)
+    whi, wlo = split16(W)
+    bd, Rd = dev(b), dev(R)
+    C_ = torch.empty(M, N, device="cuda")
+    chi = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    clo = torch.empty_like(chi)
+    check(lib().loco_op_gemm_f16x3(ptr(ahi), ptr(alo), K, ptr(whi), ptr(wlo), K, ptr(bd), ptr(Rd) if epi == 2 else None, N,
+                                   None if out_split else ptr(C_), ptr(chi) if out_split else None, ptr(clo) if out_split else None,
+                                   N, M, N, K, epi, 1, 1, 0, 0, 0, 0, stream()))
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+    if epi == 2:
+        ref = ref + R.double()
+    out = (chi.float() + clo.float()) if out_split else C_
+    assert rel_l2(out, ref) < 5e-6
