@@ -184,6 +184,12 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
                        int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2, int64_t sA1, int64_t sA2,
                        int64_t sC1, int64_t sC2, void* stream);
 
+/* split-precision attention core: q, k as fp16 hi/lo planes [B*T,768] (q pre-scaled by 1/8), v TRANSPOSED per head as
+ * planes [(b*12+head)*64+d][Tp] with Tp % 64 == 0 and zero padding for t >= T; qp/frames/ctx as loco_op_attention. */
+int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi,
+                            const void* vtlo, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
+                            int32_t Tp, void* stream);
+
 /* ---- intent head: the first consumer of the embeddings ("next" row f-1) --------------------------------------
  * IntentClassifier (/root/reference/speech_text/intent_classifier.py:24-49): pooling over time
  * (method 0 = average, 1 = max, 2 = learned-query softmax attention, :32-36) + Linear(768,101), and one

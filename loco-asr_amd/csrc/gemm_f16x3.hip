@@ -23,6 +23,51 @@ namespace loco {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
+// Shared epilogue.  v = 4 consecutive output columns n..n+3 of row m (already bias-added).
+template <int EPI, bool OUT_SPLIT>
+__device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n) {
+    if (EPI == kEpiGelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(p.R + coff + (long)m * p.ldr + n);
+    if (!OUT_SPLIT && EPI != kEpiQkvScatter) {
+        *reinterpret_cast<f32x4*>(p.C + coff + (long)m * p.ldc + n) = v;
+        return;
+    }
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        // Pin v as a rounded fp32 value first: with fp contraction hipcc folds the producing multiply into
+        // v_fma_mix*_f16 for the lo term but converts the stored hi from the fp32-rounded product -- a
+        // double-rounding mismatch worth one fp16 ulp of hi on ties.
+        asm volatile("" : "+v"(v[e]));
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    if (EPI == kEpiQkvScatter) {
+        if (n < kHidden) {  // q
+            *reinterpret_cast<h4*>(p.Chi + (long)m * kHidden + n) = hi;
+            *reinterpret_cast<h4*>(p.Clo + (long)m * kHidden + n) = lo;
+        } else if (n < 2 * kHidden) {  // k
+            *reinterpret_cast<h4*>(p.Khi + (long)m * kHidden + n - kHidden) = hi;
+            *reinterpret_cast<h4*>(p.Klo + (long)m * kHidden + n - kHidden) = lo;
+        } else {  // v, transposed per head: row (b*12 + head)*64 + d, column t
+            const int b = m / p.T, t = m - b * p.T;
+            const long row = (long)b * kHidden + (n - 2 * kHidden);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p.Vthi[(row + e) * p.Tp + t] = hi[e];
+                p.Vtlo[(row + e) * p.Tp + t] = lo[e];
+            }
+        }
+    } else {
+        const long o = coff + (long)m * p.ldc + n;
+        *reinterpret_cast<h4*>(p.Chi + o) = hi;
+        *reinterpret_cast<h4*>(p.Clo + o) = lo;
+    }
+}
+
 constexpr int SBK = 32;
 constexpr int SLD = SBK + 8;  // halves per LDS row (80 bytes)
 
@@ -166,7 +211,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16x3_kernel(GemmSplitAr
 #undef SP_GLOAD
 
     // epilogue: acc[i][j][e] = C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]
-    const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + r;
@@ -181,28 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16x3_kernel(GemmSplitAr
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (EPI == kEpiGelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
-                    const long o = coff + (long)m * p.ldc + n;
-                    if (OUT_SPLIT) {
-                        h4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            // Pin v as a rounded fp32 value first: with fp contraction hipcc folds the producing multiply
-                            // into v_fma_mix*_f16 for the lo term but converts the stored hi from the fp32-rounded
-                            // product -- a double-rounding mismatch worth one fp16 ulp of hi on ties.
-                            asm volatile("" : "+v"(v[e]));
-                            hi[e] = (_Float16)v[e];
-                            lo[e] = (_Float16)(v[e] - (float)hi[e]);
-                        }
-                        *reinterpret_cast<h4*>(p.Chi + o) = hi;
-                        *reinterpret_cast<h4*>(p.Clo + o) = lo;
-                    } else {
-                        *reinterpret_cast<f32x4*>(p.C + o) = v;
-                    }
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
                 }
             }
         }
@@ -356,7 +379,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
 #undef DMA_ISSUE
 #undef DMA_WAIT_PENDING
 
-    const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + r;
@@ -371,25 +393,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (EPI == kEpiGelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
-                    const long o = coff + (long)m * p.ldc + n;
-                    if (OUT_SPLIT) {
-                        h4 hi, lo;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            asm volatile("" : "+v"(v[e]));
-                            hi[e] = (_Float16)v[e];
-                            lo[e] = (_Float16)(v[e] - (float)hi[e]);
-                        }
-                        *reinterpret_cast<h4*>(p.Chi + o) = hi;
-                        *reinterpret_cast<h4*>(p.Clo + o) = lo;
-                    } else {
-                        *reinterpret_cast<f32x4*>(p.C + o) = v;
-                    }
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
                 }
             }
         }
@@ -403,6 +407,9 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     if (a.epilogue == kEpiResidual && (!a.R || (a.ldr & 3))) return hipErrorInvalidValue;
     const bool split = a.Chi != nullptr;
     if (split ? (a.Clo == nullptr) : (a.C == nullptr)) return hipErrorInvalidValue;
+    if (a.epilogue == kEpiQkvScatter &&
+        (!split || !a.Khi || !a.Klo || !a.Vthi || !a.Vtlo || a.N != kQkv || a.T <= 0 || a.Tp < a.T || a.nb1 * a.nb2 != 1))
+        return hipErrorInvalidValue;
     // Variant choice (tools/gemm_split_bench.py, MI355X): the LDS-DMA ring kernels win whenever there are enough rows to
     // fill 256-row tiles; the 256x256 / 16-wave form is ~5 % ahead when it still yields >= 3 full rounds of 256
     // workgroups with N a multiple of 256 (QKV, the conv layers), the 256x128 / 8-wave form otherwise; small problems
@@ -427,6 +434,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             case kEpiNone: DMA_LAUNCH(kEpiNone) break;
             case kEpiGelu: DMA_LAUNCH(kEpiGelu) break;
             case kEpiResidual: DMA_LAUNCH(kEpiResidual) break;
+            case kEpiQkvScatter: DMA_LAUNCH(kEpiQkvScatter) break;
             default: return hipErrorInvalidValue;
         }
 #undef DMA_LAUNCH
@@ -450,6 +458,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         case kEpiNone: SP_LAUNCH(kEpiNone) break;
         case kEpiGelu: SP_LAUNCH(kEpiGelu) break;
         case kEpiResidual: SP_LAUNCH(kEpiResidual) break;
+        case kEpiQkvScatter: SP_LAUNCH(kEpiQkvScatter) break;
         default: return hipErrorInvalidValue;
     }
 #undef SP_LAUNCH

@@ -89,6 +89,7 @@ struct loco_encoder {
     float* pos_w = nullptr;        // [16][128][48][48]
     SplitW conv_s[7];              // split copies of conv_w[1..6]
     SplitW proj_s;                 // feature projection
+    SplitW pe_s;                   // relative-position table pe_k [320,64]
     int precision = 0;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA for the GEMMs
     std::vector<LayerW> layers;
     float* sin_tab = nullptr;
@@ -193,7 +194,9 @@ bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     p.off_x1 = take((size_t)p.M * kHidden * f);
     p.off_tmp = take((size_t)p.M * kHidden * f);
     p.off_ctx = take((size_t)p.M * kHidden * f);
-    p.off_qkv = take((size_t)p.M * kQkv * f);
+    // fp32 [M,2304], or (precision f16x3) q and k as fp16 hi|lo planes [M,768] plus V^T planes [B*768, Tp]
+    const size_t Tp = (size_t)((p.T + 63) / 64) * 64;
+    p.off_qkv = take(((size_t)2 * p.M + (size_t)B * Tp) * kHidden * f);
     p.off_qp = take((size_t)p.M * kHeads * kRelN * f);
     p.off_ffn = take((size_t)p.M * e->cfg.ffn * f);
     p.off_xs0 = take((size_t)p.M * kHidden * f);  // fp16 hi|lo planes of x0 / x1 (precision f16x3)
@@ -247,9 +250,14 @@ int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const
 // split-precision GEMM: A and W as fp16 hi/lo planes; output fp32 (C) or planes (Chi/Clo)
 int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
                    const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
-                   int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0) {
-    GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, 1, sA1, 0, sC1, 0, epi};
-    const double nb = nb1;
+                   int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0, int nb2 = 1, long sA2 = 0, long sC2 = 0,
+                   const GemmSplitArgs* scatter = nullptr) {
+    GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epi};
+    if (scatter) {
+        a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
+        a.T = scatter->T; a.Tp = scatter->Tp;
+    }
+    const double nb = (double)nb1 * nb2;
     const double flops = 2.0 * M * (double)N * K * nb;
     const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
     Bracket br(e, s, K_GEMM_SPLIT, flops, bytes);
@@ -406,9 +414,22 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     const int T = (int)p.T;
     const long M = p.M;
     int rc;
-    float *x0 = bf.x0, *x1 = bf.x1, *tmp = bf.tmp, *qkv = bf.qkv, *qp = bf.qp;
+    float *x0 = bf.x0, *x1 = bf.x1, *tmp = bf.tmp, *qp = bf.qp;
     const int32_t* frames_or_null = bf.frames_or_null;
     const std::string pn = "prenet.", we = "wrapped_encoder.";
+    // q / k planes [M,768] and V^T planes [B*768, Tp] carved from the qkv region; the pad columns t >= T of V^T are
+    // zeroed once per forward (the QKV epilogue never writes them, attention multiplies them by P = 0)
+    const int Tp = ((T + 63) / 64) * 64;
+    _Float16* qshi = reinterpret_cast<_Float16*>(bf.qkv);
+    _Float16* qslo = qshi + (size_t)M * kHidden;
+    GemmSplitArgs scat{};
+    scat.Khi = qslo + (size_t)M * kHidden;
+    scat.Klo = scat.Khi + (size_t)M * kHidden;
+    scat.Vthi = scat.Klo + (size_t)M * kHidden;
+    scat.Vtlo = scat.Vthi + (size_t)B * kHidden * Tp;
+    scat.T = T;
+    scat.Tp = Tp;
+    HIP_TRY(hipMemsetAsync(scat.Vthi, 0, (size_t)2 * B * kHidden * Tp * sizeof(_Float16), s));
     // a fp32 buffer of n elements holds the two fp16 planes of n elements back to back
     auto planes = [](float* base, size_t n, _Float16*& hi, _Float16*& lo) {
         hi = reinterpret_cast<_Float16*>(base);
@@ -467,22 +488,24 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     planes(bf.ctx, (size_t)M * kHidden, chi, clo);
     planes(bf.ffn, (size_t)M * e->cfg.ffn, fhi, flo);
     if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden, x0hi, x0lo))) return rc;
-    const float* pe_k = W(e, we + "embed_positions.pe_k.weight");
     const int nl = e->cfg.layers;
     for (int l = 0; l < nl; ++l) {
         if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
         const std::string b = we + "layers." + std::to_string(l) + ".";
         const LayerW& lw = e->layers[l];
-        if ((rc = run_gemm_split(e, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, qkv, nullptr, nullptr, kQkv, (int)M,
-                                 kQkv, kHidden, kEpiNone)))
+        // fused q|k|v projection -> q, k as fp16 hi/lo planes, v transposed per head (the layouts attention_f16x3 reads)
+        if ((rc = run_gemm_split(e, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, nullptr, qshi, qslo, kHidden, (int)M,
+                                 kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat)))
             return rc;
-        if ((rc = run_gemm(e, s, qkv, kQkv, pe_k, kHeadDim, nullptr, nullptr, 0, qp, kRelN, T, kRelN, kHeadDim, kEpiNone, B, kHeads,
-                           (long)T * kQkv, kHeadDim, (long)kHeads * T * kRelN, (long)T * kRelN)))
+        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320]
+        if ((rc = run_gemm_split(e, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
+                                 kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN)))
             return rc;
         {
             const double tt = (double)T * T;
             Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
-            HIP_TRY(launch_attention(qkv, qp, frames_or_null, nullptr, B, T, s, chi, clo));
+            HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
+                                           Tp, s));
         }
         if ((rc = run_gemm_split(e, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), x0, kHidden, tmp, nullptr,
                                  nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
@@ -570,6 +593,7 @@ void loco_destroy(loco_encoder* e) {
     };
     for (int i = 1; i < 7; ++i) free_split(e->conv_s[i]);
     free_split(e->proj_s);
+    free_split(e->pe_s);
     for (auto& l : e->layers) {
         (void)hipFree(l.wqkv);
         (void)hipFree(l.bqkv);
@@ -673,6 +697,7 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     int rc = LOCO_OK;
     for (int i = 1; i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
     if (!rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
+    if (!rc) rc = make_split(e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
     for (int l = 0; l < e->cfg.layers && !rc; ++l) {
         LayerW& lw = e->layers[l];
         const std::string b = w + "layers." + std::to_string(l) + ".";
@@ -862,6 +887,15 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
     GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, bias, R, C,
                     (_Float16*)Chi, (_Float16*)Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epilogue};
     HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
+                            const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T, int32_t Tp, void* stream) {
+    if (!qhi || !qlo || !khi || !klo || !vthi || !vtlo || !qp || !ctx) return fail(LOCO_E_INVALID, "loco_op_attention_f16x3: null argument");
+    HIP_TRY(launch_attention_f16x3((const _Float16*)qhi, (const _Float16*)qlo, (const _Float16*)khi, (const _Float16*)klo,
+                                   (const _Float16*)vthi, (const _Float16*)vtlo, qp, frames, nullptr, nullptr, ctx, B, T, Tp,
+                                   (hipStream_t)stream));
     return LOCO_OK;
 }
 

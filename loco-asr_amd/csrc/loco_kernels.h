@@ -21,7 +21,7 @@ constexpr int kRelMax = 160;
 constexpr int kRelN = 320;
 constexpr int kQkv = 3 * kHidden;
 
-enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2 };
+enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2, kEpiQkvScatter = 3 };
 
 struct GemmArgs {
     const float* A;
@@ -52,7 +52,17 @@ struct GemmSplitArgs {
     int nb1, nb2;
     long sA1, sA2, sC1, sC2;
     int epilogue;
+    // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
+    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp]
+    _Float16* Khi = nullptr;
+    _Float16* Klo = nullptr;
+    _Float16* Vthi = nullptr;
+    _Float16* Vtlo = nullptr;
+    int T = 0, Tp = 0;
 };
+hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
+                                  const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
+                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s);
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
 hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s);
 

@@ -266,3 +266,35 @@ def test_gemm_f16x3(M, N, K, epi, out_split):
         ref = ref + R.double()
     out = (chi.float() + clo.float()) if out_split else C_
     assert rel_l2(out, ref) < 5e-6
+
+
+def planes(x):
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return hi.cuda().contiguous(), lo.cuda().contiguous()
+
+
+@pytest.mark.parametrize("B,T,frames", [(1, 1, None), (2, 200, [200, 131]), (1, 333, None), (2, 450, [450, 65]), (1, 700, [64])])
+def test_attention_core_f16x3(B, T, frames, oracle):
+    """split-precision attention vs the fp64 oracle on the SAME (hi+lo) operands: fp32-class accuracy (bar 1e-5)."""
+    qkv = hu("at.qkv", (B, T, 2304), 1.5)
+    qkv[..., :768] *= 0.125 * 1.5
+    pe_k = hu("at.pe", (320, 64), 0.9)
+    q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
+    k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
+    v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
+    qp = (q @ pe_k.t()).contiguous()
+    Tp = (T + 63) // 64 * 64
+    qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
+    kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
+    vt = torch.zeros(B, 768, Tp)
+    vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)  # [B, head*64+d, t]
+    vh, vl = planes(vt.reshape(B * 768, Tp))
+    fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
+    frd = fr.cuda() if fr is not None else None
+    qpd = dev(qp)
+    ctx = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), ptr(frd), ptr(ctx), B, T, Tp, stream()))
+    ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None if fr is None else fr.long(), q_block=128)
+    ref = ref.transpose(1, 2).reshape(B, T, 768)
+    assert rel_l2(ctx, ref) < 1e-5
