@@ -13,10 +13,12 @@ data-parallel design performs per step.  Weak scaling: every ra
 clips.  Rank 0 prints ONE JSON line; `value` = frames encoded by all ranks / max-over-ranks time.
 
 Extra objects on the line:
-  roofline      the dominant kernel (fp32-MFMA GEMM: 76 % of the FLOPs), algorithmic FLOPs / its summed launch
-                time, measured live with HIP events on the launch stream over the timed region; peak =
-                157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); traffic = PMC HBM bytes when
-                profiles/ holds them, else null.
+  roofline      the dominant kernel (the GEMM: 76 % of the FLOPs), algorithmic FLOPs / its summed launch time,
+                measured live with HIP events on the launch stream over the timed region; peak = the dense MFMA
+                rate of the instruction it issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s; MI355X_MICROARCH.md);
+                for f16x3 the 3-MFMAs-per-product issue rate is reported beside the algorithmic fraction;
+                traffic = PMC HBM bytes when profiles/ holds them, else null.
+  alt_precision the other precision mode measured for 3 steps in the same process.
   cpu_baseline  the CPU oracle (oracle/speecht5_oracle.py, torch fp32, all host cores) timed on a bounded
                 sample of the same workload (30 s clips, batch 4) on rank 0 at N = 1 -- reported, not targeted.
   embed_rel_l2  relative L2 of the GPU embeddings vs that oracle run on the sample clips (bar: 1e-3).
@@ -36,7 +38,10 @@ sys.path.insert(0, ROOT)
 
 CLIP_SECONDS = 30
 BATCH_PER_GPU = 32
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3   # dense fp32-input MFMA, MI355X_MICROARCH.md
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+DOMINANT = {"f32": ("gemm_f32", "gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, 1),
+            "f16x3": ("gemm_f16x3", "gemm_f16x3_dma_kernel", PEAK_F16_MFMA_TFLOPS, 3)}
 
 
 def host_cores() -> int:
@@ -63,6 +68,32 @@ def host_cores() -> int:
     return n
 
 
+def make_roofline(by, precision, steps):
+    """Roofline object of the dominant kernel: algorithmic FLOPs of its launches / their summed HIP-event duration."""
+    stat_name, kernel, peak, mfma_per_product = DOMINANT[precision]
+    g = by.get(stat_name)
+    if not g or g["ms"] <= 0:
+        return None
+    traffic = None
+    try:  # PMC HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{stat_name}_traffic.json")))
+        if tf:
+            traffic = json.load(open(tf[-1]))["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    r = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+         "traffic": traffic, "launches_per_step": g["launches"] / steps, "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+         "flops_per_launch_avg": g["flops"] / g["launches"], "algorithmic_bytes_per_launch_avg": g["bytes"] / g["launches"]}
+    if mfma_per_product > 1:
+        # the split algorithm issues 3 fp16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
+        r["mfma_flops_issued_per_algorithmic_flop"] = mfma_per_product
+        r["mfma_issued_tflops"] = round(ach * mfma_per_product, 1)
+        r["mfma_issued_frac_of_peak"] = round(ach * mfma_per_product / peak, 4)
+    return r
+
+
 def flops_per_clip(T: int) -> float:
     """Algorithmic FLOPs of one clip: 284.2 MFLOP*T + 36 864 FLOP*T^2."""
     return T * 284.2e6 + 36864.0 * T * T
@@ -75,8 +106,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f32",
-                    help="GEMM arithmetic: exact fp32 MFMA (default) or fp16 x3 split MFMA (fp32-class accuracy, ~2x faster)")
+    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
+                    help="contraction arithmetic: f16x3 = three fp16 MFMAs per fp32-class product (default; 3.5e-6 rel L2 of fp64), "
+                         "f32 = exact fp32 MFMA (2.3e-6), ~2x slower")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short measurement of the other precision mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-clips", type=int, default=4)
     args = ap.parse_args()
@@ -144,41 +177,44 @@ def main():
     result = None
     if rank == 0:
         by = {s["name"]: s for s in stats}
-        g = by.get("gemm_f32")
         kernels = {s["name"]: {"launches_per_step": s["launches"] / args.steps, "ms_per_step": s["ms"] / args.steps,
                                "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 and s["flops"] else None,
                                "gbps": (s["bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 and s["bytes"] else None}
                    for s in stats}
-        traffic = None
-        try:  # PMC HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
-            import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemm_traffic.json")))
-            if tf:
-                traffic = json.load(open(tf[-1]))["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        roofline = None
-        if g and g["ms"] > 0:
-            ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-            roofline = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                        "launches_per_step": g["launches"] / args.steps,
-                        "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                        "flops_per_launch_avg": g["flops"] / g["launches"],
-                        "algorithmic_bytes_per_launch_avg": g["bytes"] / g["launches"]}
+        roofline = make_roofline(by, args.precision, args.steps)
         whole = flops_per_clip(T) * B * world * args.steps / elapsed / 1e12
         result = {
             "metric": "audio frames/sec SpeechT5-base encoder, 30s×bs32 @1/2/4/8 GPU; embed L2 vs HF",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f16x3 (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)" if args.precision == "f16x3" else "f32",
+            "precision": args.precision, "data": "synthetic",
             "config": {"workload": f"SpeechT5-base speech encoder, synthetic 16 kHz {args.clip_seconds:g} s clips, batch {B} per GPU "
                                    "(BASELINE.json configs[1]), random-init weights",
                        "clip_seconds": args.clip_seconds, "batch_per_gpu": B, "global_batch": B * world, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "collective": "all_gather(embeddings)" if world > 1 else "none"},
-            "whole_path_tflops": round(whole, 2), "whole_path_frac_of_f32_mfma_peak": round(whole / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "whole_path_tflops": round(whole, 2),
             "roofline": roofline, "kernels": kernels,
         }
+        # the other precision mode, short run (3 steps), for reference
+        if world == 1 and not args.no_alt:
+            alt = "f32" if args.precision == "f16x3" else "f16x3"
+            enc.precision = alt
+            enc(input_values=x, attention_mask=m)
+            torch.cuda.synchronize()
+            enc.set_profiling(True)
+            enc.profile_reset()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                enc(input_values=x, attention_mask=m)
+            torch.cuda.synchronize()
+            ealt = time.perf_counter() - t1
+            st_alt = {s_["name"]: s_ for s_ in enc.profile_read()}
+            enc.set_profiling(False)
+            enc.precision = args.precision
+            result["alt_precision"] = {"precision": alt, "value": round(B * T * 3 / ealt, 1), "unit": "frames/s",
+                                       "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3)}
         # parity + CPU baseline on a bounded sample of the same workload (rank 0, N = 1 only)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

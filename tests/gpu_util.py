@@ -39,8 +39,9 @@ def rel_l2(a, b):
 _model_cache = {}
 
 
-def model(layers=12, seed=0):
-    """Encoder on cuda:0 loaded through the same two load_state_dict calls the reference makes."""
+def model(layers=12, seed=0, precision=None):
+    """Encoder on cuda:0 loaded through the same two load_state_dict calls the reference makes.
+    precision None = the package default ("f16x3"); the cached module's precision is reset on every call."""
     key = (layers, seed)
     if key not in _model_cache:
         sd = la.synth.encoder_state_dict(seed, layers)
@@ -49,4 +50,6 @@ def model(layers=12, seed=0):
         m.speecht5.encoder.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in enc.items()})
         m.speecht5.encoder.prenet.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
         _model_cache[key] = (m.to("cuda"), sd)
-    return _model_cache[key]
+    m, sd = _model_cache[key]
+    m.speecht5.encoder.precision = precision or "f16x3"
+    return m, sd

@@ -1,9 +1,9 @@
 """End-to-end parity of the MI355X encoder path against the golden fixtures (HuggingFace outputs generated
 in the build container, tests/golden/make_goldens.py) and against the CPU oracle run on the GPU box.
 
-Bar (BASELINE.json north_star): embeddings within 1e-3 relative L2 of the HF CPU fp32 path.  The kernels
-compute in exact fp32 (fp32-input MFMA), so the tests hold them to 1e-4 on full outputs and on every
-intermediate stage -- two fp32 evaluations of the same maths differ by ~1e-6.
+Bar (BASELINE.json north_star): embeddings within 1e-3 relative L2 of the HF CPU fp32 path.  Both precision modes
+are held to 2e-5 on full outputs and on every intermediate stage: "f32" (exact fp32 MFMA) lands at ~1e-6, the
+default "f16x3" (three fp16 MFMAs per fp32-class product) at ~3e-6.
 """
 import numpy as np
 import pytest
@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from gpu_util import la, model, rel_l2
 
-TOL = 1e-4
+TOL = 2e-5
+PRECISIONS = ["f16x3", "f32"]
 
 
-def run(lengths, mask=True, hidden=False, taps=False, layers=12):
-    m, sd = model(layers)
+def run(lengths, mask=True, hidden=False, taps=False, layers=12, precision=None):
+    m, sd = model(layers, precision=precision)
     x, msk = la.synth.batch(lengths)
     st = {} if taps else None
     out = m.speecht5.encoder(input_values=torch.from_numpy(x).cuda(),
@@ -30,19 +31,21 @@ def run(lengths, mask=True, hidden=False, taps=False, layers=12):
     return out, st, (x, msk, sd)
 
 
-def test_g1_one_second_clip_full_output():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_g1_one_second_clip_full_output(precision):
     g = golden("g1_1s.npz")
-    out, st, _ = run(g["lengths"], taps=True)
+    out, st, _ = run(g["lengths"], taps=True, precision=precision)
     assert tuple(out.last_hidden_state.shape) == (1, 49, 768)
     assert rel_l2(st["conv_stack"], g["conv_stack"]) < TOL
     assert rel_l2(st["prenet"], g["prenet"]) < TOL
     assert rel_l2(out.last_hidden_state, g["last_hidden_state"]) < TOL
 
 
-def test_g2_ragged_batch_every_stage_and_layer():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_g2_ragged_batch_every_stage_and_layer(precision):
     g = golden("g2_5s_3s.npz")
     rows = torch.from_numpy(g["rows"])
-    out, st, _ = run(g["lengths"], hidden=True, taps=True)
+    out, st, _ = run(g["lengths"], hidden=True, taps=True, precision=precision)
     assert st["frames"].cpu().tolist() == [249, 149]
     for name in ("conv_stack", "feature_projection", "prenet"):
         assert rel_l2(st[name][:, rows], g[name]) < TOL, name
@@ -53,10 +56,11 @@ def test_g2_ragged_batch_every_stage_and_layer():
     assert torch.equal(out.hidden_states[-1], out.last_hidden_state)
 
 
-def test_g3_headline_shape_batch2():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_g3_headline_shape_batch2(precision):
     g = golden("g3_30s_x2.npz")
     rows = torch.from_numpy(g["rows"])
-    out, st, _ = run(g["lengths"], hidden=True, taps=True)
+    out, st, _ = run(g["lengths"], hidden=True, taps=True, precision=precision)
     assert tuple(out.last_hidden_state.shape) == (2, 1499, 768)
     assert rel_l2(st["conv_stack"][:, rows], g["conv_stack"]) < TOL
     assert rel_l2(st["prenet"][:, rows], g["prenet"]) < TOL
@@ -65,27 +69,30 @@ def test_g3_headline_shape_batch2():
         assert abs(float(out.hidden_states[i].double().norm()) / g["hidden_stats"][i, 0] - 1) < 1e-5, i
 
 
-def test_g3r_ragged_30s():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_g3r_ragged_30s(precision):
     g = golden("g3r_30s_ragged.npz")
-    out, _, _ = run(g["lengths"])
+    out, _, _ = run(g["lengths"], precision=precision)
     y = out.last_hidden_state
     assert rel_l2(y[:, torch.from_numpy(g["rows"])], g["last_hidden_state"]) < TOL
     assert abs(float(y.double().norm()) / g["out_stats"][0] - 1) < 1e-5
 
 
-def test_g5_T4096_long_clip():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_g5_T4096_long_clip(precision):
     g = golden("g5_T4096.npz")
     rows = torch.from_numpy(g["rows"])
-    out, _, _ = run(g["lengths"], mask=False, hidden=True)
+    out, _, _ = run(g["lengths"], mask=False, hidden=True, precision=precision)
     assert tuple(out.last_hidden_state.shape) == (1, 4096, 768)
     for i in (0, 1, 6, 12):
         assert rel_l2(out.hidden_states[i][:, rows], g["hidden_states"][i]) < TOL, i
     assert abs(float(out.last_hidden_state.double().norm()) / g["hidden_stats"][12, 0] - 1) < 1e-5
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("lengths,mask", [([400], True), ([719], False), ([16000, 9600, 400], True), ([30000, 30000], False)])
-def test_against_oracle_on_the_box(lengths, mask, oracle):
-    out, _, (x, msk, sd) = run(lengths, mask=mask)
+def test_against_oracle_on_the_box(lengths, mask, oracle, precision):
+    out, _, (x, msk, sd) = run(lengths, mask=mask, precision=precision)
     ref = oracle.encode(x, msk if mask else None, sd)
     assert out.last_hidden_state.shape == ref.shape
     assert rel_l2(out.last_hidden_state, ref) < TOL
