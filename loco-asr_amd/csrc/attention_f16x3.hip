@@ -38,14 +38,27 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                                                                  const _Float16* __restrict__ vthi, const _Float16* __restrict__ vtlo,
                                                                  const float* __restrict__ qp, const int32_t* __restrict__ frames,
                                                                  _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
-                                                                 float* __restrict__ ctx, int T, int Tp) {
+                                                                 float* __restrict__ ctx, int T, int Tp, int nqb) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * AX_STAGE];
     __shared__ float bias_stage[4][32 * 17];
 
-    const int b = blockIdx.z, head = blockIdx.y;
+    // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2).  Each XCD is given a
+    // contiguous run of (clip, head, query-block) items with the query block fastest, so the query blocks of one
+    // (clip, head) -- which all stream the same K/V tiles -- run side by side on ONE L2 instead of eight.
+    int qblk, head, b;
+    {
+        const int nblk = gridDim.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qblk = w - (w / nqb) * nqb;
+        const int rest = w / nqb;
+        head = rest - (rest / kHeads) * kHeads;
+        b = rest / kHeads;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int iw0 = blockIdx.x * AX_BQ + wave * 32;
+    const int iw0 = qblk * AX_BQ + wave * 32;
     const int iq = iw0 + r;
     const int iqc = iq < T ? iq : T - 1;
 
@@ -274,13 +287,16 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
                                   _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s) {
     if (B <= 0 || T <= 0 || B > 65535 || Tp < T || (Tp % AX_BK) != 0) return hipErrorInvalidValue;
-    dim3 grid((T + AX_BQ - 1) / AX_BQ, kHeads, B);
+    const int nqb = (T + AX_BQ - 1) / AX_BQ;
+    const long nblk = (long)nqb * kHeads * B;
+    if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk);
     if (ctx_hi)
         hipLaunchKernelGGL(attention_f16x3_kernel<true>, grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qp, frames, ctx_hi, ctx_lo,
-                           ctx, T, Tp);
+                           ctx, T, Tp, nqb);
     else
         hipLaunchKernelGGL(attention_f16x3_kernel<false>, grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qp, frames, ctx_hi, ctx_lo,
-                           ctx, T, Tp);
+                           ctx, T, Tp, nqb);
     return hipGetLastError();
 }
 

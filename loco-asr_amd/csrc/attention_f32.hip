@@ -7,7 +7,7 @@
 // verified in SURVEY.md §7).  Neither the [T,T] scores nor the [T,T,64] table ever exist, so T = 29 999
 // (10-minute clips) costs memory linear in T.
 //
-// Work split: grid (T/128, 12 heads, B); 4 waves per workgroup, each wave owns 32 query rows; K/V tiles of
+// Work split: one workgroup per (query block of 128, head, clip), XCD-aware 1-D grid; 4 waves per workgroup, each wave owns 32 query rows; K/V tiles of
 // 64 keys are staged in LDS (K padded to 68 floats/row for conflict-free ds_read_b128, V unpadded: its
 // reads are lane-contiguous) and shared by the 4 waves.  Two LDS buffers, one barrier per tile; global
 // loads run two tiles ahead (they are parked in registers for one iteration, then published to the idle
@@ -42,16 +42,29 @@ template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ qkv, const float* __restrict__ qp,
                                                            const int32_t* __restrict__ frames, float* __restrict__ ctx,
                                                            _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
-                                                           int T) {
+                                                           int T, int nqb) {
     // two K/V buffers: tile t+1 is written while tile t is consumed -> ONE barrier per tile
     __shared__ __attribute__((aligned(16))) float kl[2 * AT_KT];
     __shared__ __attribute__((aligned(16))) float vl[2 * AT_VT];
     __shared__ float bias_stage[4][32 * 17];  // per-wave transpose scratch for the diagonal band (32 queries x 16 keys)
 
-    const int b = blockIdx.z, head = blockIdx.y;
+    // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2).  Each XCD is given a
+    // contiguous run of (clip, head, query-block) items with the query block fastest, so the query blocks of one
+    // (clip, head) -- which all stream the same K/V tiles -- run side by side on ONE L2 instead of eight.
+    int qblk, head, b;
+    {
+        const int nblk = gridDim.x;
+        const int q8 = nblk >> 3, r8 = nblk & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qblk = w - (w / nqb) * nqb;
+        const int rest = w / nqb;
+        head = rest - (rest / kHeads) * kHeads;
+        b = rest / kHeads;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int iw0 = blockIdx.x * AT_BQ + wave * 32;  // first query row of this wave
+    const int iw0 = qblk * AT_BQ + wave * 32;  // first query row of this wave
     const int iq = iw0 + r;
     const int iqc = iq < T ? iq : T - 1;
 
@@ -307,11 +320,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
 hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,
                             hipStream_t s, void* ctx_hi, void* ctx_lo) {
     if (B <= 0 || T <= 0 || B > 65535) return hipErrorInvalidValue;
-    dim3 grid((T + AT_BQ - 1) / AT_BQ, kHeads, B);
+    const int nqb = (T + AT_BQ - 1) / AT_BQ;
+    const long nblk = (long)nqb * kHeads * B;
+    if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
+    dim3 grid((unsigned)nblk);
     if (ctx_hi)
-        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)ctx_hi, (_Float16*)ctx_lo, T);
+        hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)ctx_hi, (_Float16*)ctx_lo, T, nqb);
     else
-        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)nullptr, (_Float16*)nullptr, T);
+        hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, s, qkv, qp, frames, ctx, (_Float16*)nullptr, (_Float16*)nullptr, T, nqb);
     return hipGetLastError();
 }
 
