@@ -9,7 +9,8 @@ architecture (no checkpoint is reachable offline).
 
 One step = one forward of the whole hot path (conv feature extractor -> 12-layer encoder) over this rank's
 batch, plus -- for N > 1 -- the single RCCL all-gather of the [32, 1499, 768] embeddings that the
-data-parallel design performs per step.  Weak scaling: every rank encodes its own 32
+data-parallel design performs per step, issued asynchronously so that it overlaps the next step's
+kernels; all K gathers complete inside the timed region.  Weak scaling: every rank encodes its own 32
 clips.  Rank 0 prints ONE JSON line; `value` = frames encoded by all ranks / max-over-ranks time.
 
 Extra objects on the line:
@@ -117,8 +118,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the encoder has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -144,12 +146,18 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     m = torch.from_numpy(m_np).to(dev)
 
+    gatherer = dp.OverlappedGather()
+
     def step():
+        # forward, then hand the embeddings to the one RCCL all-gather of the step; the collective runs on RCCL's
+        # stream under the next step's kernels and is waited for before the next one is issued (and before the clock stops)
         out = enc(input_values=x, attention_mask=m).last_hidden_state
-        return dp.all_gather_embeddings(out) if world > 1 else out
+        gatherer.submit(out)
+        return out
 
     for _ in range(args.warmup):
         y = step()
+    gatherer.finish()
     torch.cuda.synchronize()
     enc.set_profiling(True)
     enc.profile_reset()
@@ -159,11 +167,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = step()
+    gathered = gatherer.finish()  # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    assert gathered.shape[0] == world * B
     stats = enc.profile_read()
     enc.set_profiling(False)
     if world > 1:

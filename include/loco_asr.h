@@ -109,12 +109,11 @@ int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_m
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
                  size_t workspace_bytes, void* stream);
 
-/* Arithmetic of the GEMMs (conv layers 1-6, feature projection, QKV / out / FFN projections = 90 % of the FLOPs):
- *   0  exact fp32 (v_mfma_f32_32x32x2_f32)                                       -- default
- *   1  "f16x3": operands split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate;
- *      fp32-class accuracy (embeddings 3e-6 relative L2 of an fp64 evaluation vs 7e-7 for mode 0) at ~2x the speed.
- * Statistics, softmax, residuals and the attention products stay fp32 in both modes.  Takes effect at the next
- * loco_forward. */
+/* Arithmetic of the contractions (conv layers 1-6, feature projection, QKV / out / FFN projections, Qp table, QK^T, PV):
+ *   1  "f16x3" (default): operands split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32
+ *      accumulate; fp32-class accuracy (embeddings 3.5e-6 relative L2 of an fp64 evaluation) at 2x the speed of mode 0
+ *   0  exact fp32 (v_mfma_f32_32x32x2_f32): 2.3e-6
+ * Statistics, softmax, residual streams and accumulators are fp32 in both modes.  Takes effect at the next loco_forward. */
 int loco_set_precision(loco_encoder* enc, int mode);
 int loco_get_precision(const loco_encoder* enc);
 

@@ -90,7 +90,7 @@ struct loco_encoder {
     SplitW conv_s[7];              // split copies of conv_w[1..6]
     SplitW proj_s;                 // feature projection
     SplitW pe_s;                   // relative-position table pe_k [320,64]
-    int precision = 0;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA for the GEMMs
+    int precision = 1;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA (default)
     std::vector<LayerW> layers;
     float* sin_tab = nullptr;
     int sin_rows = 0;

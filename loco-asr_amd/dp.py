@@ -47,6 +47,42 @@ def all_gather_embeddings(local: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+class OverlappedGather:
+    """The per-step all-gather issued asynchronously so that it rides under the NEXT step's compute (the gathered
+    batch is only needed by the consumer -- sink or classifier -- one step later).  ``submit`` waits for the previous
+    gather, then starts this one; ``finish`` waits for the last.  Output buffers alternate between two slots."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._work = None
+        self._bufs = [None, None]
+        self._i = 0
+        self.result = None
+
+    def submit(self, local: torch.Tensor):
+        world, _ = _world(self.group)
+        if world == 1:
+            self.result = local
+            return
+        self.finish()
+        shape = (world * local.shape[0],) + tuple(local.shape[1:])
+        buf = self._bufs[self._i]
+        if buf is None or tuple(buf.shape) != shape or buf.device != local.device:
+            buf = torch.empty(shape, dtype=local.dtype, device=local.device)
+            self._bufs[self._i] = buf
+        self._src = local.contiguous()  # keep the source alive until the collective has consumed it
+        self._work = dist.all_gather_into_tensor(buf, self._src, group=self.group, async_op=True)
+        self._pending = buf
+        self._i ^= 1
+
+    def finish(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            self.result = self._pending
+        return self.result
+
+
 def gather_ragged(local: torch.Tensor, local_ids: Sequence[int], n_total: int, group=None):
     """Gather per-rank results whose batch size and padded length differ between ranks.
 

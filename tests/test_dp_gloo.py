@@ -81,3 +81,23 @@ def test_two_rank_sharded_encode_matches_single_process(tmp_path):
             for row, gid in enumerate(ids):
                 assert r0[gid].shape == ref[row].shape
                 assert torch.allclose(r0[gid], ref[row], atol=1e-5)
+
+
+def _overlap_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("loco-asr_amd.dp")
+    g = dp.OverlappedGather()
+    for step in range(3):  # what bench.py does: submit per step, finish at the end
+        g.submit(torch.full((2, 3, 4), float(10 * step + rank)))
+    out = g.finish()
+    assert out.shape == (2 * world, 3, 4)
+    for r in range(world):
+        assert float(out[2 * r, 0, 0]) == 20 + r
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_two_ranks():
+    mp.spawn(_overlap_worker, args=(2, _free_port()), nprocs=2, join=True)
