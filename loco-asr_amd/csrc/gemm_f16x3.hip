@@ -245,7 +245,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // WM x WN waves of 64x64: 4x2 = 256x128 tile, 3-stage ring (144 KiB); 4x4 = 256x256 tile, 16 waves, 2 stages (128 KiB):
 // half the L2->LDS bytes per FLOP of the 128x128 tile.
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES>
+// MF16: issue v_mfma_f32_16x16x32_f16 (16 accumulators of 16x16 per wave) instead of 32x32x16 (4 of 32x32): same FLOPs,
+// LDS bytes and registers, but the chip sustains a higher clock on that shape when the matrix pipes are the power draw.
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m, int tiles_n,
                                                                                       int nblk) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
@@ -285,14 +287,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
         const int row = 16 * (NDA * wave + u) + drow;
         int ra = m0 + row;
         ra = ra < p.M ? ra : p.M - 1;
-        ga[u] = aoff + (long)ra * p.lda + 8 * (dpos ^ ((row >> 2) & 3));
+        ga[u] = aoff + (long)ra * p.lda + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
     }
 #pragma unroll
     for (int u = 0; u < NDW; ++u) {
         const int row = 16 * (NDW * wave + u) + drow;
         int rw = n0 + row;
         rw = rw < p.N ? rw : p.N - 1;
-        gw[u] = (long)rw * p.ldw + 8 * (dpos ^ ((row >> 2) & 3));
+        gw[u] = (long)rw * p.ldw + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
     }
 #define DMA_ISSUE(kt, stage)                                                                                              \
     {                                                                                                                     \
@@ -312,13 +314,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     }
 #define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2];   // 32x32x16 form
+    f32x4 acc16[4][4];  // 16x16x32 form
+    if (MF16) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
 
     const int nk = p.K / SBK;
     constexpr int AHEAD = DSTAGES - 1;  // tiles in flight beyond the one being consumed
@@ -331,9 +341,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     }
     __builtin_amdgcn_s_barrier();
 
-    const int swz = (r >> 2) & 3;
-    const int fa = (wm * 64 + r) * SBK;  // + 32 rows * SBK for the second sub-tile; swz is the same for both
-    const int fw = (wn * 64 + r) * SBK;
+    // 32x32x16: lane (r, h) reads row r of a 32-row sub-tile, piece 2 ks + h;  16x16x32: lane (r16, q) reads row r16 of a
+    // 16-row sub-tile, piece q (one k-step per k-tile).  The stored position is piece ^ swizzle(row).
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int swz = MF16 ? 3 * ((r16 >> 2) & 1) : ((r >> 2) & 3);
+    const int fa = MF16 ? (wm * 64 + r16) * SBK + 8 * (q4 ^ swz) : (wm * 64 + r) * SBK;
+    const int fw = MF16 ? (wn * 64 + r16) * SBK + 8 * (q4 ^ swz) : (wn * 64 + r) * SBK;
 #define DMA_FRAGS(b_, ks, F)                                                                          \
     {                                                                                                 \
         const int po_ = 8 * ((2 * (ks) + h) ^ swz);                                                   \
@@ -360,11 +373,30 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
         nstage = nstage >= DSTAGES ? nstage - DSTAGES : nstage;
         if (kt + AHEAD < nk) DMA_ISSUE(kt + AHEAD, nstage)
         const _Float16* cb = lds + stage * DBUF;
-        h8 fx[8], fy[8];
-        DMA_FRAGS(cb, 0, fx)
-        DMA_FRAGS(cb, 1, fy)
-        DMA_MFMA(fx)
-        DMA_MFMA(fy)
+        if (MF16) {
+            h8 ah[4], al[4], wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(cb + fa + 16 * i * SBK);
+                al[i] = *reinterpret_cast<const h8*>(cb + DPA + fa + 16 * i * SBK);
+                wh[i] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + 16 * i * SBK);
+                wl[i] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + 16 * i * SBK);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc16[i][j], 0, 0, 0);
+                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc16[i][j], 0, 0, 0);
+                }
+        } else {
+            h8 fx[8], fy[8];
+            DMA_FRAGS(cb, 0, fx)
+            DMA_FRAGS(cb, 1, fy)
+            DMA_MFMA(fx)
+            DMA_MFMA(fy)
+        }
         // retire the next tile; with a 3-stage ring the newest tile's DMAs stay in flight across the barrier
         if (AHEAD == 2 && kt + 2 < nk) {
             DMA_WAIT_PENDING()
@@ -379,6 +411,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
 #undef DMA_ISSUE
 #undef DMA_WAIT_PENDING
 
+    if (MF16) {
+        // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + 16 * i + r16;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * j + 4 * q4;
+                if (n < p.N) {
+                    f32x4 v = acc16[i][j];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + r;
@@ -422,13 +472,17 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         const long nb = (long)tm * tn * a.nb1 * a.nb2;
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
         const bool sp = a.Chi != nullptr;
-#define DMA_LAUNCH(EPI)                                                                                                                \
-        if (dma == 2) {                                                                                                                \
-            if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, 4, 4, 2>), dim3((unsigned)nb), dim3(1024), 0, s, a, tm, tn, (int)nb); \
-            else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, 4, 4, 2>), dim3((unsigned)nb), dim3(1024), 0, s, a, tm, tn, (int)nb);   \
-        } else {                                                                                                                       \
-            if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, 4, 2, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, tn, (int)nb);  \
-            else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, 4, 2, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, tn, (int)nb);    \
+        // MFMA shape: 16x16x32 measured +12..24 % over 32x32x16 on every encoder shape at identical FLOPs / LDS bytes / registers
+        // (QKV 296 -> 332, FFN1 242 -> 300, conv1 313 -> 377 TFLOP/s algorithmic): the chip holds a higher clock on it.
+        constexpr bool mf32 = false;
+#define DMA_LAUNCH2(EPI, SP, MF)                                                                                                        \
+        if (dma == 2) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, SP, 4, 4, 2, MF>), dim3((unsigned)nb), dim3(1024), 0, s, a, tm, tn, (int)nb); \
+        else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, SP, 4, 2, 3, MF>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, tn, (int)nb);
+#define DMA_LAUNCH(EPI)                                        \
+        if (sp) {                                              \
+            if (mf32) { DMA_LAUNCH2(EPI, true, false) } else { DMA_LAUNCH2(EPI, true, true) }     \
+        } else {                                               \
+            if (mf32) { DMA_LAUNCH2(EPI, false, false) } else { DMA_LAUNCH2(EPI, false, true) }   \
         }
         switch (a.epilogue) {
             case kEpiNone: DMA_LAUNCH(kEpiNone) break;
@@ -438,6 +492,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             default: return hipErrorInvalidValue;
         }
 #undef DMA_LAUNCH
+#undef DMA_LAUNCH2
         return hipGetLastError();
     }
     const bool big = false;
