@@ -25,12 +25,23 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // Shared epilogue.  v = 4 consecutive output columns n..n+3 of row m (already bias-added).
 template <int EPI, bool OUT_SPLIT>
-__device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n) {
+__device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n, int z1 = 0, int z2 = 0) {
     if (EPI == kEpiGelu) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
     }
     if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(p.R + coff + (long)m * p.ldr + n);
+    if (EPI == kEpiPosConv) {  // hidden + GELU(conv + bias) + sinusoid (HF modeling:555-564); z1 = clip, z2 = group, m = frame
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        int nvalid = p.frames ? p.frames[z1] : p.T;
+        if (nvalid <= 0 || nvalid > p.T) nvalid = p.T;
+        const int pos = m < nvalid ? m + 2 : 1;
+        v += *reinterpret_cast<const f32x4*>(p.R + coff + (long)m * p.ldr + n);
+        v += *reinterpret_cast<const f32x4*>(p.sin_table + (long)pos * kHidden + z2 * kPosCg + n);
+        *reinterpret_cast<f32x4*>(p.C + coff + (long)m * p.ldc + n) = v;
+        return;
+    }
     if (!OUT_SPLIT && EPI != kEpiQkvScatter) {
         *reinterpret_cast<f32x4*>(p.C + coff + (long)m * p.ldc + n) = v;
         return;
@@ -247,15 +258,20 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // half the L2->LDS bytes per FLOP of the 128x128 tile.
 // MF16: issue v_mfma_f32_16x16x32_f16 (16 accumulators of 16x16 per wave) instead of 32x32x16 (4 of 32x32): same FLOPs,
 // LDS bytes and registers, but the chip sustains a higher clock on that shape when the matrix pipes are the power draw.
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16>
+// NJ: 16-column sub-tiles each wave actually computes (4, or 3 when N = 48: the positional conv's 48 outputs per group).
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m, int tiles_n,
                                                                                       int nblk) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
     constexpr int DPA = DBM * SBK, DPW = DBN * SBK;  // halves per A / W plane
     constexpr int DBUF = 2 * DPA + 2 * DPW;
-    constexpr int NDA = DBM / 16 / NW_, NDW = DBN / 16 / NW_;  // 16-row DMA pieces per wave per plane
-    constexpr int NDMA = 2 * NDA + 2 * NDW;                     // DMA instructions per wave per k-tile
-    static_assert(NDA >= 1 && NDW >= 1, "tile too small for the wave count");
+    constexpr int NDA = DBM / 16 / NW_;                                // 16-row DMA pieces per wave per A plane
+    constexpr int NDW = (DBN / 16 + NW_ - 1) / NW_;                    // ... per W plane (the last waves may have none)
+    constexpr int WPIECES = DBN / 16;
+    constexpr int NDMA = 2 * NDA + 2 * NDW;                            // DMA instructions per wave per k-tile
+    static_assert(NDA >= 1, "tile too small for the wave count");
+    static_assert(WPIECES % NW_ == 0 || DSTAGES == 2, "uneven W pieces need the 2-stage ring (vmcnt(0) waits only)");
+    static_assert(NJ == 4 || MF16, "NJ < 4 is implemented for the 16x16x32 path");
     __shared__ __attribute__((aligned(16))) _Float16 lds[DSTAGES * DBUF];
 
     int mt, nt, z;
@@ -271,6 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     const int z1 = z / p.nb2, z2 = z % p.nb2;
     const long aoff = z1 * p.sA1 + z2 * p.sA2;
     const long coff = z1 * p.sC1 + z2 * p.sC2;
+    const long woff = z2 * p.sW2;
     const int m0 = mt * DBM, n0 = nt * DBN;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
         const int row = 16 * (NDW * wave + u) + drow;
         int rw = n0 + row;
         rw = rw < p.N ? rw : p.N - 1;
-        gw[u] = (long)rw * p.ldw + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
+        gw[u] = woff + (long)rw * p.ldw + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
     }
 #define DMA_ISSUE(kt, stage)                                                                                              \
     {                                                                                                                     \
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
             __builtin_amdgcn_global_load_lds((gptr_t)(p.Alo + ga[u] + (long)(kt) * SBK),                                  \
                                              (lptr_t)(b_ + DPA + 16 * (NDA * wave + u) * SBK), 16, 0, 0);                 \
         }                                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < NDW; ++u) {                                                                 \
+        _Pragma("unroll") for (int u = 0; u < NDW; ++u) if (WPIECES % NW_ == 0 || NDW * wave + u < WPIECES) {             \
             __builtin_amdgcn_global_load_lds((gptr_t)(p.Whi + gw[u] + (long)(kt) * SBK),                                  \
                                              (lptr_t)(b_ + 2 * DPA + 16 * (NDW * wave + u) * SBK), 16, 0, 0);             \
             __builtin_amdgcn_global_load_lds((gptr_t)(p.Wlo + gw[u] + (long)(kt) * SBK),                                  \
@@ -315,12 +332,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
 #define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
     f32x16 acc[2][2];   // 32x32x16 form
-    f32x4 acc16[4][4];  // 16x16x32 form
+    f32x4 acc16[4][NJ];  // 16x16x32 form
     if (MF16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -374,18 +391,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
         if (kt + AHEAD < nk) DMA_ISSUE(kt + AHEAD, nstage)
         const _Float16* cb = lds + stage * DBUF;
         if (MF16) {
-            h8 ah[4], al[4], wh[4], wl[4];
+            h8 ah[4], al[4], wh[NJ], wl[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 ah[i] = *reinterpret_cast<const h8*>(cb + fa + 16 * i * SBK);
                 al[i] = *reinterpret_cast<const h8*>(cb + DPA + fa + 16 * i * SBK);
-                wh[i] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + 16 * i * SBK);
-                wl[i] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + 16 * i * SBK);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + 16 * j * SBK);
+                wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + 16 * j * SBK);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc16[i][j], 0, 0, 0);
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc16[i][j], 0, 0, 0);
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc16[i][j], 0, 0, 0);
@@ -418,12 +438,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
             const int m = m0 + wm * 64 + 16 * i + r16;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * 64 + 16 * j + 4 * q4;
                 if (n < p.N) {
                     f32x4 v = acc16[i][j];
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, z1, z2);
                 }
             }
         }
@@ -460,6 +480,16 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     if (a.epilogue == kEpiQkvScatter &&
         (!split || !a.Khi || !a.Klo || !a.Vthi || !a.Vtlo || a.N != kQkv || a.T <= 0 || a.Tp < a.T || a.nb1 * a.nb2 != 1))
         return hipErrorInvalidValue;
+    if (a.epilogue == kEpiPosConv) {
+        // grouped positional conv: N = 48 outputs per group -> 512 x 64 tile (8 x 1 waves, 3 of 4 column sub-tiles computed)
+        if (a.N != kPosCg || !a.C || !a.R || !a.sin_table || a.T <= 0 || split) return hipErrorInvalidValue;
+        const int tm = (a.M + 511) / 512;
+        const long nb = (long)tm * a.nb1 * a.nb2;
+        if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
+                           (int)nb);
+        return hipGetLastError();
+    }
     // Variant choice (tools/gemm_split_bench.py, MI355X): the LDS-DMA ring kernels win whenever there are enough rows to
     // fill 256-row tiles; the 256x256 / 16-wave form is ~5 % ahead when it still yields >= 3 full rounds of 256
     // workgroups with N a multiple of 256 (QKV, the conv layers), the 256x128 / 8-wave form otherwise; small problems
@@ -533,6 +563,57 @@ __global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restri
         reinterpret_cast<h4*>(hi)[i] = a;
         reinterpret_cast<h4*>(lo)[i] = b;
     }
+}
+
+// x [B,T,768] -> group-major hi/lo planes [B][16][T+128][48] with 64 zero frames of halo on both sides
+__global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int T,
+                                         long total4) {
+    const int rows = T + kPosK;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (kPosCg / 4));
+        long rest = i / (kPosCg / 4);
+        const int row = (int)(rest % rows);
+        rest /= rows;
+        const int g = (int)(rest % kPosGroups);
+        const int b = (int)(rest / kPosGroups);
+        const int t = row - kPosK / 2;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < T) v = *reinterpret_cast<const f32x4*>(x + ((long)b * T + t) * kHidden + g * kPosCg + 4 * c4);
+        h4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = (_Float16)v[e];
+            c[e] = (_Float16)(v[e] - (float)a[e]);
+        }
+        reinterpret_cast<h4*>(hi)[i] = a;
+        reinterpret_cast<h4*>(lo)[i] = c;
+    }
+}
+
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipErrorInvalidValue;
+    const long total4 = (long)B * kPosGroups * (T + kPosK) * (kPosCg / 4);
+    hipLaunchKernelGGL(group_major_split_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, T, total4);
+    return hipGetLastError();
+}
+
+// [g][tap][o][i] -> [g][o][tap][i]
+__global__ void pos_w_for_gemm_kernel(const float* __restrict__ wf, float* __restrict__ out) {
+    const long total = (long)kHidden * kPosCg * kPosK;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % kPosCg);
+        long rest = idx / kPosCg;
+        const int tap = (int)(rest % kPosK);
+        rest /= kPosK;
+        const int o = (int)(rest % kPosCg);
+        const int g = (int)(rest / kPosCg);
+        out[idx] = wf[(((long)g * kPosK + tap) * kPosCg + o) * kPosCg + i];
+    }
+}
+
+hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(pos_w_for_gemm_kernel, dim3(1024), dim3(256), 0, s, wf, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s) {

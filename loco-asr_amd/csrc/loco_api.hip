@@ -90,6 +90,7 @@ struct loco_encoder {
     SplitW conv_s[7];              // split copies of conv_w[1..6]
     SplitW proj_s;                 // feature projection
     SplitW pe_s;                   // relative-position table pe_k [320,64]
+    SplitW posg_s;                 // positional conv weight as the GEMM's W: [16][48][128*48]
     int precision = 1;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA (default)
     std::vector<LayerW> layers;
     float* sin_tab = nullptr;
@@ -198,7 +199,9 @@ bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     const size_t Tp = (size_t)((p.T + 63) / 64) * 64;
     p.off_qkv = take(((size_t)2 * p.M + (size_t)B * Tp) * kHidden * f);
     p.off_qp = take((size_t)p.M * kHeads * kRelN * f);
-    p.off_ffn = take((size_t)p.M * e->cfg.ffn * f);
+    // FFN intermediate [M,3072]; doubles as scratch for the group-major positional-conv operand [B,16,T+128,48] x 2 planes
+    const size_t ffn_elems = (size_t)p.M * e->cfg.ffn, posg_elems = (size_t)B * (p.T + kPosK) * kHidden;
+    p.off_ffn = take((ffn_elems > posg_elems ? ffn_elems : posg_elems) * f);
     p.off_xs0 = take((size_t)p.M * kHidden * f);  // fp16 hi|lo planes of x0 / x1 (precision f16x3)
     p.off_xs1 = take((size_t)p.M * kHidden * f);
     p.total = o;
@@ -474,10 +477,30 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         return rc;
     if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
 
-    // ---- positional conv + sinusoid (fp32 MFMA kernel)
+    // ---- positional conv + sinusoid as ONE split GEMM per (clip, group): x1 is re-laid group-major with a 64-frame zero
+    // halo, so that output frame t reads the contiguous run of 128 taps x 48 channels (lda = 48, K = 6144); the epilogue
+    // fuses bias, GELU, the residual x1 and the sinusoidal-position gather (HF :389-397,555-564)
     {
+        _Float16* ghi = reinterpret_cast<_Float16*>(bf.ffn);  // scratch: the FFN buffer is idle until the first layer
+        _Float16* glo = ghi + (size_t)B * kPosGroups * (T + kPosK) * kPosCg;
+        {
+            Bracket br(e, s, K_COPY, 0.0, 8.0 * M * kHidden);
+            HIP_TRY(launch_group_major_split(x1, ghi, glo, B, T, s));
+        }
+        GemmSplitArgs a{};
+        a.Ahi = ghi; a.Alo = glo; a.Whi = e->posg_s.hi; a.Wlo = e->posg_s.lo;
+        a.bias = W(e, pn + "pos_conv_embed.conv.bias");
+        a.R = x1; a.C = x0;
+        a.M = T; a.N = kPosCg; a.K = kPosK * kPosCg;
+        a.lda = kPosCg; a.ldw = (long)kPosK * kPosCg; a.ldc = kHidden; a.ldr = kHidden;
+        a.nb1 = B; a.nb2 = kPosGroups;
+        a.sA1 = (long)kPosGroups * (T + kPosK) * kPosCg; a.sA2 = (long)(T + kPosK) * kPosCg;
+        a.sC1 = (long)T * kHidden; a.sC2 = kPosCg;
+        a.sW2 = (long)kPosCg * kPosK * kPosCg; a.sBias2 = kPosCg;
+        a.epilogue = kEpiPosConv;
+        a.sin_table = e->sin_tab; a.frames = frames_or_null; a.T = T;
         Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
-        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
+        HIP_TRY(launch_gemm_split(a, s));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
 
@@ -594,6 +617,7 @@ void loco_destroy(loco_encoder* e) {
     for (int i = 1; i < 7; ++i) free_split(e->conv_s[i]);
     free_split(e->proj_s);
     free_split(e->pe_s);
+    free_split(e->posg_s);
     for (auto& l : e->layers) {
         (void)hipFree(l.wqkv);
         (void)hipFree(l.bqkv);
@@ -698,6 +722,16 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     for (int i = 1; i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
     if (!rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
     if (!rc) rc = make_split(e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
+    if (!rc) {  // positional conv weight re-laid [g][o][tap*48+i] for the conv-as-GEMM form, then split
+        float* tmpw = nullptr;
+        const size_t n = (size_t)kHidden * kPosCg * kPosK;
+        HIP_TRY(hipMalloc(&tmpw, n * sizeof(float)));
+        hipError_t he = launch_pos_w_for_gemm(e->pos_w, tmpw, s);
+        if (he == hipSuccess) rc = make_split(e->posg_s, tmpw, n, s);
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(tmpw);
+        if (he != hipSuccess) return fail(LOCO_E_HIP, "pos_w_for_gemm: %s", hipGetErrorString(he));
+    }
     for (int l = 0; l < e->cfg.layers && !rc; ++l) {
         LayerW& lw = e->layers[l];
         const std::string b = w + "layers." + std::to_string(l) + ".";

@@ -21,7 +21,7 @@ constexpr int kRelMax = 160;
 constexpr int kRelN = 320;
 constexpr int kQkv = 3 * kHidden;
 
-enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2, kEpiQkvScatter = 3 };
+enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2, kEpiQkvScatter = 3, kEpiPosConv = 4 };
 
 struct GemmArgs {
     const float* A;
@@ -59,7 +59,18 @@ struct GemmSplitArgs {
     _Float16* Vthi = nullptr;
     _Float16* Vtlo = nullptr;
     int T = 0, Tp = 0;
+    // kEpiPosConv (grouped positional conv as a GEMM over the group-major halo layout, see launch_group_major_split):
+    // z1 = clip, z2 = group; C = R + GELU(acc + bias) + sin_table[pos(t)], pos = t+2 for t < frames[z1] else 1
+    long sW2 = 0;                   // weight stride per z2 (0 = shared weights)
+    long sBias2 = 0;                // bias stride per z2
+    const float* sin_table = nullptr;
+    const int32_t* frames = nullptr;
 };
+// x [B,T,768] fp32 -> fp16 hi/lo planes in group-major layout [B][16][T+128][48] with 64 zero frames before and after:
+// output frame t of group g then reads the CONTIGUOUS run rows t .. t+127 (128 taps x 48 channels = K 6144, lda = 48)
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s);
+// folded positional-conv weight [g][tap][o][i] -> [g][o][tap*48 + i] (the GEMM's W, ldw = 6144)
+hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s);
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
                                   _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s);
