@@ -31,6 +31,20 @@ def shard_units(lengths: Sequence[int], world_size: int, rank: int) -> List[int]
     return order[rank::world_size]
 
 
+def window_units(lengths: Sequence[int], window: int, min_samples: int = 400) -> List[Tuple[int, int, int]]:
+    """BASELINE.json configs[3]: long recordings (60-minute podcasts) are cut into fixed windows (10 minutes) that are
+    encoded as independent units.  Returns (recording index, first sample, end sample) per window in recording order;
+    a trailing piece shorter than one encoder frame (400 samples) is dropped."""
+    units = []
+    for i, n in enumerate(lengths):
+        n = int(n)
+        for a in range(0, n, window):
+            b = min(n, a + window)
+            if b - a >= min_samples:
+                units.append((i, a, b))
+    return units
+
+
 def _world(group=None) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)

@@ -106,6 +106,9 @@ def main(argv=None):
     ap.add_argument("--do-normalize", action="store_true")
     ap.add_argument("--format", choices=["pickle", "npy"], default="pickle")
     ap.add_argument("--gather", action="store_true", help="all-gather embeddings so that rank 0 writes everything")
+    ap.add_argument("--window-seconds", type=float, default=0.0,
+                    help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
+                         "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
     args = ap.parse_args(argv)
     if args.modality == "text":
         raise SystemExit("-m text: the text prenet path is outside the MI355X hot path (SURVEY.md §2a rows 1-2)")
@@ -140,6 +143,24 @@ def main(argv=None):
             classes = sorted({it[4] for it in items})
         fetch = lambda i: load_audio_16k(items[i][2])
         lengths = [0] * len(items)  # unknown until decoded: keep corpus order within a rank
+    if args.window_seconds > 0:
+        # windows become the units: (id_wk, text, path, sr, label) with a fetch that slices the parent recording
+        win = int(args.window_seconds * 16000)
+        if not any(lengths):
+            lengths = [len(fetch(i)) for i in range(len(items))]
+        units = dp.window_units(lengths, win)
+        parent_fetch, parent_items = fetch, items
+        cache = {}
+
+        def fetch(u, _units=units):  # noqa: E731 -- one decode per recording, sliced per window
+            i, a, b = _units[u]
+            if i not in cache:
+                cache.clear()
+                cache[i] = parent_fetch(i)
+            return cache[i][a:b]
+        items = [(f"{parent_items[i][0]}_w{a // win:03d}", parent_items[i][1], parent_items[i][2], 16000, parent_items[i][4])
+                 for (i, a, b) in units]
+        lengths = [b - a for (_, a, b) in units]
     print(f"{args.split} set size: {len(items)}")
     encode_labels = one_hot_encoder(classes)
 

@@ -66,3 +66,24 @@ def test_extract_then_train_head_pipeline(tmp_path):
     sd = torch.load(ck / "speecht5_attention_audio_best.pth")
     assert set(sd) == {"q", "classifier.0.weight", "classifier.0.bias"}
     assert np.isfinite(tl)
+
+
+def test_extract_cli_windows(tmp_path, oracle):
+    """--window-seconds: a 2.5 s synthetic clip cut into 1 s windows -> 3 units, each equal to encoding that slice alone."""
+    la = importlib.import_module("loco-asr_amd")
+    extract = importlib.import_module("loco-asr_amd.extract")
+    out = str(tmp_path / "w")
+    extract.main(["-m", "audio", "-s", "test", "--synthetic", "1", "--synthetic-seconds", "5", "--random-init", "--window-seconds", "1",
+                  "--batch-size", "4", "--out", out])
+    n = la.synth.mixed_lengths(1, 80000)[0]
+    clip = la.synth.clip(0, n)
+    files = sorted(os.listdir(os.path.join(out, "test", "audio")))
+    nwin = (n + 15999) // 16000 if n % 16000 >= 400 or n % 16000 == 0 else n // 16000
+    assert len(files) == nwin and files[0] == "synthetic-000000_w000_embedding_and_target.pickle"
+    sd = la.synth.encoder_state_dict(0)
+    with open(os.path.join(out, "test", "audio", files[1]), "rb") as fh:
+        d = pickle.load(fh)
+    ref = oracle.encode(clip[None, 16000:32000], None, sd)[0].numpy()
+    # windows of equal length batched together are independent units
+    assert d["embedding"].shape == ref.shape
+    assert np.linalg.norm(d["embedding"] - ref) / np.linalg.norm(ref) < 1e-4

@@ -147,3 +147,15 @@ def test_fairseq_checkpoint_mapping_round_trip():
     assert not r1.missing_keys and not r1.unexpected_keys and not r2.missing_keys and not r2.unexpected_keys
     _, _, unm = cm.map_fairseq_speecht5({"encoder.layers.0.mystery.weight": 1})
     assert unm == ["encoder.layers.0.mystery.weight"]
+
+
+def test_window_units_for_long_recordings():
+    """configs[3]: 60-minute recordings -> 10-minute windows as independent units."""
+    hour, ten = 60 * 60 * 16000, 10 * 60 * 16000
+    u = dp.window_units([hour, ten + 5, 399, 2 * ten + 400], ten)
+    assert [x for x in u if x[0] == 0] == [(0, k * ten, (k + 1) * ten) for k in range(6)]
+    assert [x for x in u if x[0] == 1] == [(1, 0, ten)]  # the 5-sample tail is shorter than a frame: dropped
+    assert [x for x in u if x[0] == 2] == []
+    assert [x for x in u if x[0] == 3] == [(3, 0, ten), (3, ten, 2 * ten), (3, 2 * ten, 2 * ten + 400)]
+    shards = [dp.shard_units([b - a for _, a, b in u], 8, r) for r in range(8)]
+    assert sorted(i for s in shards for i in s) == list(range(len(u)))
