@@ -298,3 +298,50 @@ def test_attention_core_f16x3(B, T, frames, oracle):
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None if fr is None else fr.long(), q_block=128)
     ref = ref.transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 1e-5
+
+
+@pytest.mark.parametrize("epi,out_split", [(0, False), (1, True), (2, False)])
+def test_gemm_f16x3_large_tiles(epi, out_split):
+    """Shapes that take the 256x256 / 16-wave LDS-DMA kernel (>= 768 tiles of 256x256) with a ragged last row tile."""
+    M, N, K = 22001, 2304, 256
+    A = hu("g4.a", (M, K), 2.0)
+    W = hu("g4.w", (N, K), 2.0 / math.sqrt(K))
+    b = hu("g4.b", (N,))
+    R = hu("g4.r", (M, N))
+    ahi, alo = split16(A)
+    whi, wlo = split16(W)
+    bd, Rd = dev(b), dev(R)
+    C_ = torch.empty(M, N, device="cuda")
+    chi = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    clo = torch.empty_like(chi)
+    check(lib().loco_op_gemm_f16x3(ptr(ahi), ptr(alo), K, ptr(whi), ptr(wlo), K, ptr(bd), ptr(Rd) if epi == 2 else None, N,
+                                   None if out_split else ptr(C_), ptr(chi) if out_split else None, ptr(clo) if out_split else None,
+                                   N, M, N, K, epi, 1, 1, 0, 0, 0, 0, stream()))
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+    if epi == 2:
+        ref = ref + R.double()
+    out = (chi.float() + clo.float()) if out_split else C_
+    assert rel_l2(out, ref) < 5e-6
+
+
+def test_gemm_f16x3_batched_strided_conv_large():
+    """conv layer as a batched split GEMM on the big-tile kernel: 9 clips x 12 001 frames, k=3, stride 2."""
+    Cc, k, s_, Tin, B = 512, 3, 2, 24003, 9
+    x = hu("c4.x", (B, Tin, Cc))
+    w = hu("c4.w", (Cc, Cc, k), math.sqrt(2.0 / (Cc * k)))
+    Tout = (Tin - k) // s_ + 1
+    wt = w.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    xhi, xlo = split16(x)
+    whi, wlo = split16(wt)
+    chi = torch.empty(B * Tout, Cc, dtype=torch.float16, device="cuda")
+    clo = torch.empty_like(chi)
+    check(lib().loco_op_gemm_f16x3(ptr(xhi), ptr(xlo), s_ * Cc, ptr(whi), ptr(wlo), k * Cc, None, None, Cc, None, ptr(chi), ptr(clo), Cc,
+                                   Tout, Cc, k * Cc, 1, B, 1, Tin * Cc, 0, Tout * Cc, 0, stream()))
+    idx = torch.tensor([0, 1, 4000, Tout - 2, Tout - 1])
+    ref = F.conv1d(x.transpose(1, 2).double(), w.double(), stride=s_)
+    ref = (0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))).transpose(1, 2)  # [B,Tout,C]
+    out = (chi.float() + clo.float()).view(B, Tout, Cc).cpu()
+    assert rel_l2(out[:, idx], ref[:, idx]) < 5e-6
+    assert rel_l2(out, ref) < 5e-6
