@@ -23,6 +23,8 @@
 namespace loco {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int AX_BQ = 128, AX_BK = 64;
@@ -196,13 +198,18 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[0][e]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[1][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) + cb;
+        {   // the other lane half holds the other 32 keys of this query: one permlane32 swap instead of an LDS permute
+            const unsigned mu = __builtin_bit_cast(unsigned, mx);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) + cb;
+        }
 
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
         m_run = m_new;
         const float dsh = (cb - m_new) * kLog2e;
-        float ps = 0.f;
+        f32x2 ps2 = {0.f, 0.f};
+        const f32x2 k2 = {kLog2e, kLog2e}, d2 = {dsh, dsh};
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
@@ -213,15 +220,23 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         for (int st = 0; st < 2; ++st) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                h8 ph, pl;
+                // p = exp2(s log2e + dsh); hi = fp16(p) packed by one cvt_pk per pair, lo = fp16(p - hi) by one mixed-precision
+                // FMA per element (fp32 p, fp16 hi: the difference is exact, so lo is rounded once, like the host split)
+                u32x4 uh, ul;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[st][8 * s2 + j], kLog2e, dsh));
-                    ps += pv;
-                    asm volatile("" : "+v"(pv));
-                    ph[j] = (_Float16)pv;
-                    pl[j] = (_Float16)(pv - (float)ph[j]);
+                for (int jp = 0; jp < 4; ++jp) {
+                    const f32x2 sx = {s[st][8 * s2 + 2 * jp], s[st][8 * s2 + 2 * jp + 1]};
+                    const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(ax.x), __builtin_amdgcn_exp2f(ax.y)};
+                    ps2 += pv;
+                    unsigned hi, lo;
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(pv.x), "v"(pv.y));
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(pv.x), "v"(hi));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(pv.y), "v"(hi));
+                    uh[jp] = hi;
+                    ul[jp] = lo;
                 }
+                const h8 ph = __builtin_bit_cast(h8, uh), pl = __builtin_bit_cast(h8, ul);
                 const int kofs = 32 * st + 16 * s2 + 4 * h;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 }
             }
         }
-        l_run = l_run * alpha + ps;
+        l_run = l_run * alpha + (ps2.x + ps2.y);
 
         __syncthreads();
         cur ^= 1;
