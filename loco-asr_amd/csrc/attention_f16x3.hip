@@ -28,11 +28,25 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int AX_BQ = 128, AX_BK = 64;
-constexpr int AX_LDK = kHeadDim + 8;   // halves per K row
-constexpr int AX_LDV = AX_BK + 4;      // halves per V^T row
-constexpr int AX_KPL = AX_BK * AX_LDK; // halves per K plane
-constexpr int AX_VPL = kHeadDim * AX_LDV;
-constexpr int AX_STAGE = 2 * AX_KPL + 2 * AX_VPL;
+constexpr int AX_PL = AX_BK * kHeadDim;  // halves per plane of a tile (64 x 64, unpadded: XOR-swizzled 16-byte pieces)
+constexpr int AX_STG = 2 * AX_PL;        // hi + lo plane
+
+typedef __attribute__((address_space(1))) const void* ax_gptr_t;
+typedef __attribute__((address_space(3))) void* ax_lptr_t;
+
+#define AX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define AX_PIN() __builtin_amdgcn_sched_barrier(0)
+
+// p = exp2(s log2e + dsh) for a register pair; hi = fp16(p) by one cvt_pk, lo = fp16(p - hi) by one mixed-precision FMA per
+// element (fp32 p, fp16 hi: the difference is exact, so lo is rounded once, like the host-side split).
+__device__ __forceinline__ void ax_split_pair(const f32x2 pv, unsigned& hi, unsigned& lo) {
+    // The s_nop is load-bearing: pv usually comes straight from v_exp_f32, and gfx950 needs one wait state between a
+    // transcendental result and a VALU reader.  hipcc pads its own instructions but does not look inside inline asm
+    // (seen as wrong results in the lanes the quarter-rate unit finishes last).
+    asm("s_nop 0\n\tv_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(pv.x), "v"(pv.y));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(pv.x), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(pv.y), "v"(hi));
+}
 
 template <bool OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16* __restrict__ qhi, const _Float16* __restrict__ qlo,
@@ -41,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                                                                  const float* __restrict__ qp, const int32_t* __restrict__ frames,
                                                                  _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
                                                                  float* __restrict__ ctx, int T, int Tp, int nqb) {
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * AX_STAGE];
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4 * AX_STG];  // K ring (2 tiles), V^T ring (2 tiles)
     __shared__ float bias_stage[4][32 * 17];
 
     // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2).  Each XCD is given a
@@ -83,187 +97,253 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     const float c_past = qprow[kRelN - 1];  // i - j >= 159
     const float c_future = qprow[0];        // i - j <= -160
 
-    // staging: 16-byte piece f = tid + 256 u of a 64 x 128-byte plane tile -> row f/8, piece f%8 (8 halves)
-    const int srow = tid >> 3, spc = (tid & 7) * 8;
-    const long kbase = (long)b * T * kHidden + head * kHeadDim + spc;
-    const long vbase = ((long)b * kHidden + head * kHeadDim) * Tp + spc;
-    h8 sk[4], sv[4];  // [hi u0, hi u1, lo u0, lo u1]
-#define AX_LOAD_TILE(t)                                                                    \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                        \
-        int j_ = (t) * AX_BK + srow + 32 * u;                                              \
-        j_ = j_ < T ? j_ : T - 1;                                                          \
-        sk[u] = *reinterpret_cast<const h8*>(khi + kbase + (long)j_ * kHidden);            \
-        sk[2 + u] = *reinterpret_cast<const h8*>(klo + kbase + (long)j_ * kHidden);        \
-        const long vo_ = vbase + (long)(srow + 32 * u) * Tp + (long)(t) * AX_BK;           \
-        sv[u] = *reinterpret_cast<const h8*>(vthi + vo_);                                  \
-        sv[2 + u] = *reinterpret_cast<const h8*>(vtlo + vo_);                              \
+    // LDS-DMA descriptors: one wave instruction writes 1 KiB = 8 rows x 8 pieces of 16 bytes; lane -> row lane/8, stored
+    // position lane%8, which holds source piece position ^ swz(row), swz(row) = {row bit 4, row bit 3, row bit 1}.
+    // ds_read_b128 serves a wave in four fixed groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over 64
+    // banks: with one 128-byte row per lane the 16 lanes of a group must cover both row parities x 8 distinct pieces,
+    // which is exactly what those three row bits separate (checked with SQ_LDS_BANK_CONFLICT = 0).
+    const int drow = lane >> 3, dpos = lane & 7;
+    long kcol[2], vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int swz = (((2 * wave + i) & 3) << 1) | ((drow >> 1) & 1);
+        kcol[i] = (long)head * kHeadDim + 8 * (dpos ^ swz);
+        vsrc[i] = ((long)b * kHidden + head * kHeadDim + 8 * (2 * wave + i) + drow) * Tp + 8 * (dpos ^ swz);
     }
-#define AX_STORE_TILE(st_)                                                                                       \
-    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                              \
-        _Float16* kb_ = lds + (st_) * AX_STAGE + (srow + 32 * u) * AX_LDK + spc;                                 \
-        *reinterpret_cast<h8*>(kb_) = sk[u];                                                                     \
-        *reinterpret_cast<h8*>(kb_ + AX_KPL) = sk[2 + u];                                                        \
-        _Float16* vb_ = lds + (st_) * AX_STAGE + 2 * AX_KPL + (srow + 32 * u) * AX_LDV + spc;                    \
-        *reinterpret_cast<h4*>(vb_) = __builtin_shufflevector(sv[u], sv[u], 0, 1, 2, 3);                         \
-        *reinterpret_cast<h4*>(vb_ + 4) = __builtin_shufflevector(sv[u], sv[u], 4, 5, 6, 7);                     \
-        *reinterpret_cast<h4*>(vb_ + AX_VPL) = __builtin_shufflevector(sv[2 + u], sv[2 + u], 0, 1, 2, 3);        \
-        *reinterpret_cast<h4*>(vb_ + AX_VPL + 4) = __builtin_shufflevector(sv[2 + u], sv[2 + u], 4, 5, 6, 7);    \
+#define AX_DMA_K(t_, stg_)                                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                 \
+        int j_ = (t_) * AX_BK + 8 * (2 * wave + i_) + drow;                                                            \
+        j_ = j_ < T ? j_ : T - 1;                                                                                      \
+        const long go_ = ((long)b * T + j_) * kHidden + kcol[i_];                                                         \
+        _Float16* d_ = lds + (stg_) * AX_STG + 8 * (2 * wave + i_) * kHeadDim;                                         \
+        __builtin_amdgcn_global_load_lds((ax_gptr_t)(khi + go_), (ax_lptr_t)d_, 16, 0, 0);                             \
+        __builtin_amdgcn_global_load_lds((ax_gptr_t)(klo + go_), (ax_lptr_t)(d_ + AX_PL), 16, 0, 0);                   \
     }
+#define AX_DMA_V(t_, stg_)                                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                 \
+        const long go_ = vsrc[i_] + (long)(t_) * AX_BK;                                                                \
+        _Float16* d_ = lds + (2 + (stg_)) * AX_STG + 8 * (2 * wave + i_) * AX_BK;                                      \
+        __builtin_amdgcn_global_load_lds((ax_gptr_t)(vthi + go_), (ax_lptr_t)d_, 16, 0, 0);                            \
+        __builtin_amdgcn_global_load_lds((ax_gptr_t)(vtlo + go_), (ax_lptr_t)(d_ + AX_PL), 16, 0, 0);                  \
+    }
+
+    // fragment addresses (halves, within a tile): row 32 x + r, piece (2 y + h) ^ swz(r); x = key sub-tile (K) or d half
+    // (V^T), y = k-step (K) or 16-key group (V^T: the keys of a group are stored in the order the P operand wants, see
+    // loco_kernels.h, so one 16-byte piece per lane half is a whole A fragment)
+    int fo[4];
+    {
+        const int swz = (((r >> 3) & 3) << 1) | ((r >> 1) & 1);
+#pragma unroll
+        for (int y = 0; y < 4; ++y) fo[y] = r * kHeadDim + 8 * ((2 * y + h) ^ swz);
+    }
+#define AX_KF(kb_, st_, ks_, pl_) (*reinterpret_cast<const h8*>((kb_) + (pl_) * AX_PL + (st_) * 32 * kHeadDim + fo[ks_]))
+#define AX_VF(vb_, dt_, c_, pl_) (*reinterpret_cast<const h8*>((vb_) + (pl_) * AX_PL + (dt_) * 32 * AX_BK + fo[c_]))
 
     f32x16 o0, o1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
+    float alpha = 0.f, dsh = 0.f;  // of the tile whose scores sit in (sa0, sa1) / (sb0, sb1) at the top of an iteration
 
-    AX_LOAD_TILE(0)
-    AX_STORE_TILE(0)
-    if (ntiles > 1) { AX_LOAD_TILE(1) }
+    // ---- relative-position bias, key mask, row max and the online-softmax bookkeeping for one tile's raw scores.
+    //      mx_ is the max of the raw scores (valid for tiles with a constant bias and no mask; recomputed otherwise).
+#define AX_BAND(S_, st_)                                                                                               \
+    _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                           \
+        const int j = j0 + 32 * (st_) + 16 * half + lj;                                                                \
+        float bv[8];                                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
+            const int i = iw0 + 4 * u + lq;                                                                            \
+            int rel = i - j;                                                                                           \
+            rel = rel < -kRelMax ? -kRelMax : (rel > kRelMax - 1 ? kRelMax - 1 : rel);                                 \
+            bv[u] = qpb[(long)(i < T ? i : T - 1) * kRelN + rel + kRelMax];                                            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bv[u];                              \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+        _Pragma("unroll") for (int e8 = 0; e8 < 8; ++e8)                                                               \
+            S_[8 * half + e8] += sc[r * 17 + (e8 & 3) + 8 * (e8 >> 2) + 4 * h];                                        \
+        __builtin_amdgcn_wave_barrier();                                                                               \
+    }
+#define AX_FINISH_TILE(S0_, S1_, tt_, mx_)                                                                             \
+    {                                                                                                                  \
+        const int j0 = (tt_) * AX_BK;                                                                                  \
+        const int dmin = iw0 - (j0 + AX_BK - 1);                                                                       \
+        const int dmax = iw0 + 31 - j0;                                                                                \
+        float cb = 0.f;                                                                                                \
+        bool redo = false;                                                                                             \
+        if (dmin >= kRelMax - 1) {                                                                                     \
+            cb = c_past;                                                                                               \
+        } else if (dmax <= -kRelMax) {                                                                                 \
+            cb = c_future;                                                                                             \
+        } else {                                                                                                       \
+            float* sc = bias_stage[wave];                                                                              \
+            const float* qpb = qp + ((long)b * kHeads + head) * T * kRelN;                                             \
+            const int lj = lane & 15, lq = lane >> 4;                                                                  \
+            AX_BAND(S0_, 0)                                                                                            \
+            AX_BAND(S1_, 1)                                                                                            \
+            redo = true;                                                                                               \
+        }                                                                                                              \
+        if (j0 + AX_BK > nvalid) {                                                                                     \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                           \
+                const int j = j0 + (e & 3) + 8 * (e >> 2) + 4 * h;                                                     \
+                S0_[e] = j < nvalid ? S0_[e] : -INFINITY;                                                              \
+                S1_[e] = j + 32 < nvalid ? S1_[e] : -INFINITY;                                                         \
+            }                                                                                                          \
+            redo = true;                                                                                               \
+        }                                                                                                              \
+        float mxv = (mx_);                                                                                             \
+        if (redo) {                                                                                                    \
+            mxv = S0_[0];                                                                                              \
+            _Pragma("unroll") for (int e = 1; e < 16; ++e) mxv = fmaxf(mxv, S0_[e]);                                   \
+            _Pragma("unroll") for (int e = 0; e < 16; ++e) mxv = fmaxf(mxv, S1_[e]);                                   \
+        }                                                                                                              \
+        {   /* the other lane half holds the other 32 keys of this query: one permlane32 swap, no LDS permute */       \
+            const unsigned mu = __builtin_bit_cast(unsigned, mxv);                                                     \
+            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);                                    \
+            mxv = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) + cb;                      \
+        }                                                                                                              \
+        const float m_new = fmaxf(m_run, mxv);                                                                         \
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);                                                      \
+        m_run = m_new;                                                                                                 \
+        dsh = (cb - m_new) * kLog2e;                                                                                   \
+    }
+
+    // ---- prologue: K(0), V(0), K(1) in flight; S(0) = K(0) Q^T and its bookkeeping
+    AX_DMA_K(0, 0)
+    AX_DMA_V(0, 0)
+    if (ntiles > 1) { AX_DMA_K(1, 1) }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int cur = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const _Float16* kb = lds + cur * AX_STAGE;
-        const _Float16* vb = kb + 2 * AX_KPL;
-        if (t + 1 < ntiles) {
-            AX_STORE_TILE(cur ^ 1)
-            if (t + 2 < ntiles) { AX_LOAD_TILE(t + 2) }
+    f32x16 sa0, sa1, sb0, sb1;
+    {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sa0[e] = 0.f; sa1[e] = 0.f; }
+        const _Float16* kb = lds;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const h8 kh0 = AX_KF(kb, 0, ks, 0), kl0 = AX_KF(kb, 0, ks, 1), kh1 = AX_KF(kb, 1, ks, 0), kl1 = AX_KF(kb, 1, ks, 1);
+            sa0 = AX_MFMA(kl0, qh[ks], sa0); sa1 = AX_MFMA(kl1, qh[ks], sa1);
+            sa0 = AX_MFMA(kh0, ql[ks], sa0); sa1 = AX_MFMA(kh1, ql[ks], sa1);
+            sa0 = AX_MFMA(kh0, qh[ks], sa0); sa1 = AX_MFMA(kh1, qh[ks], sa1);
         }
-        const int j0 = t * AX_BK;
-
-        // ---- S^T = K Q^T: 2 sub-tiles x 4 k-steps x 3 MFMAs
-        f32x16 s[2];
+        float mx = sa0[0];
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sa0[e]);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[st][e] = 0.f;
-            const _Float16* kr = kb + (st * 32 + r) * AX_LDK + 8 * h;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h8 kh = *reinterpret_cast<const h8*>(kr + 16 * ks);
-                const h8 kl = *reinterpret_cast<const h8*>(kr + AX_KPL + 16 * ks);
-                s[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s[st], 0, 0, 0);
-                s[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s[st], 0, 0, 0);
-                s[st] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s[st], 0, 0, 0);
-            }
-        }
-        // scores stay in natural units; log2(e) is folded into the exponent FMA below
-        // ---- relative-position bias + key mask (see attention_f32.hip)
-        const int dmin = iw0 - (j0 + AX_BK - 1);
-        const int dmax = iw0 + 31 - j0;
-        float cb = 0.f;
-        if (dmin >= kRelMax - 1) {
-            cb = c_past;
-        } else if (dmax <= -kRelMax) {
-            cb = c_future;
-        } else {
-            float* sc = bias_stage[wave];
-            const float* qpb = qp + ((long)b * kHeads + head) * T * kRelN;
-            const int lj = lane & 15, lq = lane >> 4;
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int j = j0 + 32 * st + 16 * half + lj;
-                    float bv[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int i = iw0 + 4 * u + lq;
-                        int rel = i - j;
-                        rel = rel < -kRelMax ? -kRelMax : (rel > kRelMax - 1 ? kRelMax - 1 : rel);
-                        bv[u] = qpb[(long)(i < T ? i : T - 1) * kRelN + rel + kRelMax];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bv[u];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) {
-                        const int e = 8 * half + e8;
-                        s[st][e] += sc[r * 17 + (e8 & 3) + 8 * (e8 >> 2) + 4 * h];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-        if (j0 + AX_BK > nvalid) {
-#pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int j = j0 + 32 * st + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    s[st][e] = j < nvalid ? s[st][e] : -INFINITY;
-                }
-        }
-        float mx = s[0][0];
-#pragma unroll
-        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[0][e]);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[1][e]);
-        {   // the other lane half holds the other 32 keys of this query: one permlane32 swap instead of an LDS permute
-            const unsigned mu = __builtin_bit_cast(unsigned, mx);
-            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-            mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) + cb;
-        }
-
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);
-        m_run = m_new;
-        const float dsh = (cb - m_new) * kLog2e;
-        f32x2 ps2 = {0.f, 0.f};
-        const f32x2 k2 = {kLog2e, kLog2e}, d2 = {dsh, dsh};
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { o0[e] *= alpha; o1[e] *= alpha; }
-        }
-
-        // ---- O^T += V^T P^T: per sub-tile 2 k-steps; P split in registers, V^T runs of 4 keys from the [d][key] image
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                // p = exp2(s log2e + dsh); hi = fp16(p) packed by one cvt_pk per pair, lo = fp16(p - hi) by one mixed-precision
-                // FMA per element (fp32 p, fp16 hi: the difference is exact, so lo is rounded once, like the host split)
-                u32x4 uh, ul;
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    const f32x2 sx = {s[st][8 * s2 + 2 * jp], s[st][8 * s2 + 2 * jp + 1]};
-                    const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);
-                    const f32x2 pv = {__builtin_amdgcn_exp2f(ax.x), __builtin_amdgcn_exp2f(ax.y)};
-                    ps2 += pv;
-                    unsigned hi, lo;
-                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(pv.x), "v"(pv.y));
-                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(pv.x), "v"(hi));
-                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(pv.y), "v"(hi));
-                    uh[jp] = hi;
-                    ul[jp] = lo;
-                }
-                const h8 ph = __builtin_bit_cast(h8, uh), pl = __builtin_bit_cast(h8, ul);
-                const int kofs = 32 * st + 16 * s2 + 4 * h;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const _Float16* vr = vb + (32 * dt + r) * AX_LDV + kofs;
-                    const h4 a0 = *reinterpret_cast<const h4*>(vr), a1 = *reinterpret_cast<const h4*>(vr + 8);
-                    const h4 c0 = *reinterpret_cast<const h4*>(vr + AX_VPL), c1 = *reinterpret_cast<const h4*>(vr + AX_VPL + 8);
-                    const h8 vh = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const h8 vl = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    if (dt == 0) {
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o0, 0, 0, 0);
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o0, 0, 0, 0);
-                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o0, 0, 0, 0);
-                    } else {
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o1, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o1, 0, 0, 0);
-                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o1, 0, 0, 0);
-                    }
-                }
-            }
-        }
-        l_run = l_run * alpha + (ps2.x + ps2.y);
-
-        __syncthreads();
-        cur ^= 1;
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa1[e]);
+        AX_FINISH_TILE(sa0, sa1, 0, mx)
     }
-#undef AX_LOAD_TILE
-#undef AX_STORE_TILE
+    __syncthreads();  // every wave has read K(0) before K(2) may land on it
+
+    // ---- main loop, software-pipelined inside each wave so that the matrix pipe and the vector ALU always have
+    //      independent work from the SAME wave (two waves per SIMD cannot be relied on to fall into anti-phase):
+    //        block 1:  S(t+1) = K(t+1) Q^T   (24 MFMAs)  ||  exp2 + hi/lo split of S(t) keys 0..31, exp2 of keys 32..63
+    //        block 2:  O += V(t)[0..31] P     (12 MFMAs)  ||  hi/lo split of keys 32..63
+    //        block 3:  O += V(t)[32..63] P    (12 MFMAs)  ||  raw row max of S(t+1)
+    //      K(t+2) and V(t+1) stream into the rings by LDS-DMA meanwhile.  SC = scores of tile t (consumed), SN = tile t+1.
+#define AX_ITER(t_, SC0, SC1, SN0, SN1)                                                                                \
+    {                                                                                                                  \
+        const int tq = (t_);                                                                                           \
+        if (tq + 2 < ntiles) { AX_DMA_K(tq + 2, tq & 1) }                                                              \
+        if (tq + 1 < ntiles) { AX_DMA_V(tq + 1, (tq + 1) & 1) }                                                        \
+        const _Float16* kb = lds + ((tq + 1) & 1) * AX_STG;                                                            \
+        const _Float16* vb = lds + (2 + (tq & 1)) * AX_STG;                                                            \
+        h8 kf[2][4]; /* [buffer][hi0, lo0, hi1, lo1] */                                                                \
+        kf[0][0] = AX_KF(kb, 0, 0, 0); kf[0][1] = AX_KF(kb, 0, 0, 1);                                                  \
+        kf[0][2] = AX_KF(kb, 1, 0, 0); kf[0][3] = AX_KF(kb, 1, 0, 1);                                                  \
+        const f32x2 al2 = {alpha, alpha}, k2 = {kLog2e, kLog2e}, d2 = {dsh, dsh};                                      \
+        f32x2 ps2 = {0.f, 0.f};                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 16; e += 2) {                                                            \
+            f32x2 a_ = {o0[e], o0[e + 1]}, c_ = {o1[e], o1[e + 1]};                                                    \
+            a_ *= al2; c_ *= al2;                                                                                      \
+            o0[e] = a_.x; o0[e + 1] = a_.y; o1[e] = c_.x; o1[e + 1] = c_.y;                                            \
+        }                                                                                                              \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) { SN0[e] = 0.f; SN1[e] = 0.f; }                                 \
+        u32x4 ph0[2], pl0[2], ph1[2], pl1[2];                                                                          \
+        AX_PIN();                                                                                                      \
+        /* ---- block 1 */                                                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                             \
+            if (ks + 1 < 4) {                                                                                          \
+                kf[(ks + 1) & 1][0] = AX_KF(kb, 0, ks + 1, 0); kf[(ks + 1) & 1][1] = AX_KF(kb, 0, ks + 1, 1);          \
+                kf[(ks + 1) & 1][2] = AX_KF(kb, 1, ks + 1, 0); kf[(ks + 1) & 1][3] = AX_KF(kb, 1, ks + 1, 1);          \
+            }                                                                                                          \
+            _Pragma("unroll") for (int m = 0; m < 6; ++m) {                                                            \
+                const int st = m & 1, wh = m >> 1;                                                                     \
+                const h8 a_ = kf[ks & 1][2 * st + (wh == 0 ? 1 : 0)];                                                  \
+                const h8 b_ = wh == 1 ? ql[ks] : qh[ks];                                                               \
+                if (st == 0) SN0 = AX_MFMA(a_, b_, SN0); else SN1 = AX_MFMA(a_, b_, SN1);                              \
+                const int n = 6 * ks + m, q_ = n / 3;                                                                  \
+                if (n % 3 == 0) {                                                                                      \
+                    const int e0 = 2 * q_;                                                                             \
+                    const f32x2 sx = {SC0[e0], SC0[e0 + 1]};                                                           \
+                    const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);                                            \
+                    const f32x2 pv = {__builtin_amdgcn_exp2f(ax.x), __builtin_amdgcn_exp2f(ax.y)};                     \
+                    ps2 += pv;                                                                                         \
+                    asm volatile("" : "+v"(ps2));                                                                      \
+                    unsigned hi_, lo_;                                                                                 \
+                    ax_split_pair(pv, hi_, lo_);                                                                       \
+                    ph0[q_ >> 2][q_ & 3] = hi_; pl0[q_ >> 2][q_ & 3] = lo_;                                            \
+                } else if (n % 3 == 1) {                                                                               \
+                    const int e0 = 2 * q_;                                                                             \
+                    const f32x2 sx = {SC1[e0], SC1[e0 + 1]};                                                           \
+                    const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);                                            \
+                    SC1[e0] = __builtin_amdgcn_exp2f(ax.x); SC1[e0 + 1] = __builtin_amdgcn_exp2f(ax.y);                \
+                }                                                                                                      \
+                AX_PIN();                                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        /* ---- blocks 2 and 3: 8 groups (st, s2, dt) of 3 MFMAs; V^T fragments one group ahead */                     \
+        h8 vf[2][2]; /* [buffer][hi, lo] */                                                                            \
+        vf[0][0] = AX_VF(vb, 0, 0, 0); vf[0][1] = AX_VF(vb, 0, 0, 1);                                                  \
+        float mxr = -INFINITY;                                                                                         \
+        _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                \
+            const int st = g >> 2, s2 = (g >> 1) & 1, dt = g & 1;                                                      \
+            if (g + 1 < 8) {                                                                                           \
+                const int c1 = (g + 1) >> 1, dt1 = (g + 1) & 1;                                                        \
+                vf[(g + 1) & 1][0] = AX_VF(vb, dt1, c1, 0); vf[(g + 1) & 1][1] = AX_VF(vb, dt1, c1, 1);                \
+            }                                                                                                          \
+            const h8 vh = vf[g & 1][0], vl = vf[g & 1][1];                                                             \
+            const h8 ph = __builtin_bit_cast(h8, st == 0 ? ph0[s2] : ph1[s2]);                                         \
+            const h8 pl = __builtin_bit_cast(h8, st == 0 ? pl0[s2] : pl1[s2]);                                         \
+            _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                            \
+                const h8 a_ = m == 0 ? vl : vh;                                                                        \
+                const h8 b_ = m == 1 ? pl : ph;                                                                        \
+                if (dt == 0) o0 = AX_MFMA(a_, b_, o0); else o1 = AX_MFMA(a_, b_, o1);                                  \
+                const int n = 3 * g + m;                                                                               \
+                if (n < 8) { /* block 2: split keys 32..63 (already exponentiated in place) */                         \
+                    const f32x2 pv = {SC1[2 * n], SC1[2 * n + 1]};                                                     \
+                    ps2 += pv;                                                                                         \
+                    asm volatile("" : "+v"(ps2));                                                                      \
+                    unsigned hi_, lo_;                                                                                 \
+                    ax_split_pair(pv, hi_, lo_);                                                                       \
+                    ph1[n >> 2][n & 3] = hi_; pl1[n >> 2][n & 3] = lo_;                                                \
+                } else if (n >= 12 && n < 20) { /* block 3: raw max of the next tile, 4 values per slot */             \
+                    const int e0 = 4 * (n - 12);                                                                       \
+                    if (e0 < 16) mxr = fmaxf(fmaxf(fmaxf(mxr, SN0[e0]), fmaxf(SN0[e0 + 1], SN0[e0 + 2])), SN0[e0 + 3]); \
+                    else mxr = fmaxf(fmaxf(fmaxf(mxr, SN1[e0 - 16]), fmaxf(SN1[e0 - 15], SN1[e0 - 14])), SN1[e0 - 13]); \
+                    asm volatile("" : "+v"(mxr));                                                                      \
+                }                                                                                                      \
+                AX_PIN();                                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        l_run = l_run * alpha + (ps2.x + ps2.y);                                                                       \
+        if (tq + 1 < ntiles) { AX_FINISH_TILE(SN0, SN1, tq + 1, mxr) }                                                 \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
+        __syncthreads();                                                                                               \
+    }
+
+    for (int t = 0; t < ntiles; t += 2) {
+        AX_ITER(t, sa0, sa1, sb0, sb1)
+        if (t + 1 >= ntiles) break;
+        AX_ITER(t + 1, sb0, sb1, sa0, sa1)
+    }
+#undef AX_ITER
+#undef AX_FINISH_TILE
+#undef AX_BAND
+#undef AX_DMA_K
+#undef AX_DMA_V
+#undef AX_KF
+#undef AX_VF
 
     // ---- normalise and store: o{0,1}[e] = O[iq][d = 32 dt + (e&3) + 8 (e>>2) + 4h]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

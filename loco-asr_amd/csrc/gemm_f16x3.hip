@@ -63,13 +63,14 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
         } else if (n < 2 * kHidden) {  // k
             *reinterpret_cast<h4*>(p.Khi + (long)m * kHidden + n - kHidden) = hi;
             *reinterpret_cast<h4*>(p.Klo + (long)m * kHidden + n - kHidden) = lo;
-        } else {  // v, transposed per head: row (b*12 + head)*64 + d, column t
+        } else {  // v, transposed per head: row (b*12 + head)*64 + d, column vt_col(t) (loco_kernels.h)
             const int b = m / p.T, t = m - b * p.T;
             const long row = (long)b * kHidden + (n - 2 * kHidden);
+            const int tc = vt_col(t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                p.Vthi[(row + e) * p.Tp + t] = hi[e];
-                p.Vtlo[(row + e) * p.Tp + t] = lo[e];
+                p.Vthi[(row + e) * p.Tp + tc] = hi[e];
+                p.Vtlo[(row + e) * p.Tp + tc] = lo[e];
             }
         }
     } else {

@@ -53,7 +53,8 @@ struct GemmSplitArgs {
     long sA1, sA2, sC1, sC2;
     int epilogue;
     // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
-    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp]
+    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp],
+    // frame t in column vt_col(t)
     _Float16* Khi = nullptr;
     _Float16* Klo = nullptr;
     _Float16* Vthi = nullptr;
@@ -78,6 +79,11 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
 hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s);
 
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
+// Column of frame t in a V^T plane row: bits 2 and 3 of t are swapped, i.e. each aligned group of 16 frames is stored as
+// [0-3, 8-11, 4-7, 12-15].  That is the order in which one lane half of the 32x32x16 MFMA holds 8 of the 16 keys of a
+// k-step in the P operand (attention_f16x3.hip), so the matching V^T fragment is ONE contiguous 16-byte piece.
+__host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);

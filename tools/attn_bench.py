@@ -25,6 +25,8 @@ def run(B, T, reps, check=False, ragged=False):
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
     vt = torch.zeros(B, 768, Tp, device="cuda")
     vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)
+    tt = torch.arange(Tp, device="cuda")
+    vt = vt[:, :, (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)].contiguous()  # column of frame t: bits 2 and 3 swapped
     vh, vl = planes(vt.reshape(B * 768, Tp))
     fr = None
     if ragged:
@@ -45,7 +47,7 @@ def run(B, T, reps, check=False, ragged=False):
     if check:
         qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2)
         kd = (kh.double() + kl.double()).view(B, T, 12, 64).transpose(1, 2)
-        vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., :T].transpose(2, 3)
+        vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)][..., :T].transpose(2, 3)
         i = torch.arange(T, device="cuda")
         rel = (i[:, None] - i[None, :]).clamp(-160, 159) + 160
         bias = torch.gather(qp.double(), 3, rel[None, None].expand(B, 12, T, T))
