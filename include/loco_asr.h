@@ -185,8 +185,9 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
 
 /* split-precision attention core: q, k as fp16 hi/lo planes [B*T,768] (q pre-scaled by 1/8), v TRANSPOSED per head as
  * planes [(b*12+head)*64+d][Tp] with Tp % 64 == 0 and zero padding for t >= T, frame t stored in column
- * (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)  (bits 2 and 3 of t swapped: the order the matrix instruction consumes
+ * loco_op_vt_column(t) (a permutation inside each aligned group of 16 frames: the order the matrix instruction consumes
  * keys in, which is what the fused q|k|v projection writes); qp/frames/ctx as loco_op_attention. */
+int32_t loco_op_vt_column(int32_t t);
 int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi,
                             const void* vtlo, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
                             int32_t Tp, void* stream);

@@ -906,6 +906,8 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
     return LOCO_OK;
 }
 
+int32_t loco_op_vt_column(int32_t t) { return loco::vt_col(t); }
+
 int loco_op_split_f16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
     if (!x || !hi || !lo || n <= 0 || (n & 3)) return fail(LOCO_E_INVALID, "loco_op_split_f16: invalid argument");
     HIP_TRY(launch_split_f16(x, hi, lo, n, (hipStream_t)stream));

@@ -80,8 +80,11 @@ hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStrea
 
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
 // Column of frame t in a V^T plane row: bits 2 and 3 of t are swapped, i.e. each aligned group of 16 frames is stored as
-// [0-3, 8-11, 4-7, 12-15].  That is the order in which one lane half of the 32x32x16 MFMA holds 8 of the 16 keys of a
-// k-step in the P operand (attention_f16x3.hip), so the matching V^T fragment is ONE contiguous 16-byte piece.
+// [0-3, 8-11, 4-7, 12-15].  The split-precision attention feeds P straight from the S^T accumulator registers into the
+// next MFMA as its B operand; a lane half then holds keys {4h..4h+3, 8+4h..8+4h+3} of a 16-key k-step, and with this
+// column order the matching V^T fragment is ONE contiguous 16-byte piece (attention_f16x3.hip).  (The 16x16x32 MFMA
+// shape was built too -- it wants bits (b4 b3 b2) -> (b3 b2 b4) inside groups of 32 -- and ran only 2 % faster: this
+// kernel is not limited by the matrix pipe's power the way the GEMM is, so the simpler 32x32x16 form stays.)
 __host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -289,8 +289,10 @@ def test_attention_core_f16x3(B, T, frames, oracle):
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
     vt = torch.zeros(B, 768, Tp)
     vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)  # [B, head*64+d, t]
-    tt = torch.arange(Tp)
-    vt = vt[:, :, (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)]  # frame t lives in column swap_bits_2_3(t) (an involution)
+    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
+    vtp = torch.zeros_like(vt)
+    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
+    vt = vtp
     vh, vl = planes(vt.reshape(B * 768, Tp))
     fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
     frd = fr.cuda() if fr is not None else None

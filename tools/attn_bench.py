@@ -5,6 +5,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 la = importlib.import_module("loco-asr_amd")
 lib = la._lib.load()
+if len(sys.argv) > 1:  # A/B another build of the library inside the same process (same device, same clocks)
+    alt = C.CDLL(os.path.abspath(sys.argv[1]))
+    for name in ("loco_op_attention_f16x3", "loco_op_vt_column"):
+        getattr(alt, name).restype = getattr(lib, name).restype
+        getattr(alt, name).argtypes = getattr(lib, name).argtypes
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 
 
@@ -13,7 +18,7 @@ def planes(x):
     return hi.contiguous(), (x - hi.float()).half().contiguous()
 
 
-def run(B, T, reps, check=False, ragged=False):
+def run(B, T, reps, check=False, ragged=False, use_alt=False):
     g = torch.Generator(device="cuda").manual_seed(1)
     qkv = (torch.rand(B, T, 2304, device="cuda", generator=g) - 0.5) * 3.0
     qkv[..., :768] *= 0.125 * 1.5
@@ -25,15 +30,18 @@ def run(B, T, reps, check=False, ragged=False):
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
     vt = torch.zeros(B, 768, Tp, device="cuda")
     vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)
-    tt = torch.arange(Tp, device="cuda")
-    vt = vt[:, :, (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)].contiguous()  # column of frame t: bits 2 and 3 swapped
+    col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
+    vtp = torch.zeros_like(vt)
+    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
+    vt = vtp
     vh, vl = planes(vt.reshape(B * 768, Tp))
     fr = None
     if ragged:
         fr = torch.tensor([T - (i * 37) % (T // 2) for i in range(B)], dtype=torch.int32, device="cuda")
     ctx = torch.empty(B, T, 768, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    call = lambda: lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st)
+    L = alt if use_alt else lib
+    call = lambda: L.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st)
     assert call() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,11 +51,11 @@ def run(B, T, reps, check=False, ragged=False):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 4.0 * B * 12 * T * T * 64
-    msg = f"B={B} T={T} ragged={ragged}: {ms:.3f} ms  {fl / ms * 1e-9:.1f} TFLOP/s algorithmic  checksum {float(ctx.double().abs().sum()):.9e}"
+    msg = f"{'alt ' if use_alt else 'main'} B={B} T={T} ragged={ragged}: {ms:.3f} ms  {fl / ms * 1e-9:.1f} TFLOP/s algorithmic  checksum {float(ctx.double().abs().sum()):.9e}"
     if check:
         qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2)
         kd = (kh.double() + kl.double()).view(B, T, 12, 64).transpose(1, 2)
-        vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)][..., :T].transpose(2, 3)
+        vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., col][..., :T].transpose(2, 3)
         i = torch.arange(T, device="cuda")
         rel = (i[:, None] - i[None, :]).clamp(-160, 159) + 160
         bias = torch.gather(qp.double(), 3, rel[None, None].expand(B, 12, T, T))
@@ -62,6 +70,12 @@ def run(B, T, reps, check=False, ragged=False):
 if __name__ == "__main__":
     run(2, 700, 3, check=True, ragged=True)
     run(1, 1499, 3, check=True)
-    run(32, 1499, 20)
+    variants = [False, True] if len(sys.argv) > 1 else [False]
+    if len(sys.argv) > 1:
+        run(2, 700, 3, check=True, ragged=True, use_alt=True)
+    for rep in range(3 if len(sys.argv) > 1 else 1):
+        for v in variants:
+            run(32, 1499, 40, use_alt=v)
+        for v in variants:
+            run(1, 29999, 5, use_alt=v)
     run(32, 1499, 20, ragged=True)
-    run(1, 29999, 3)

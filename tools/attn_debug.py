@@ -21,8 +21,10 @@ def run(B, T, nvalid=None, zero_bias=False):
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
     vt = torch.zeros(B, 768, Tp, device="cuda")
     vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)
-    tt = torch.arange(Tp, device="cuda")
-    vt = vt[:, :, (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)].contiguous()  # column of frame t: bits 2 and 3 swapped
+    col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
+    vtp = torch.zeros_like(vt)
+    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
+    vt = vtp
     vh, vl = planes(vt.reshape(B * 768, Tp))
     fr = None if nvalid is None else torch.tensor(nvalid, dtype=torch.int32, device="cuda")
     ctx = torch.zeros(B, T, 768, device="cuda")
@@ -31,7 +33,7 @@ def run(B, T, nvalid=None, zero_bias=False):
     torch.cuda.synchronize()
     qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2)
     kd = (kh.double() + kl.double()).view(B, T, 12, 64).transpose(1, 2)
-    vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., (tt & ~12) | ((tt & 4) << 1) | ((tt & 8) >> 1)][..., :T].transpose(2, 3)
+    vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., col][..., :T].transpose(2, 3)
     i = torch.arange(T, device="cuda")
     rel = (i[:, None] - i[None, :]).clamp(-160, 159) + 160
     s = qd @ kd.transpose(2, 3) + torch.gather(qp.double(), 3, rel[None, None].expand(B, 12, T, T))
