@@ -80,6 +80,63 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
     }
 }
 
+// 16 consecutive output columns n..n+15 of row m (v[j] = columns n+4j..n+4j+3, bias added): the LDS-DMA kernel hands each
+// lane such a run (see the W-row permutation there), so planes are written as 16-byte pieces and a row's four lanes
+// complete whole 128-byte lines instead of 8-byte fragments.
+template <int EPI, bool OUT_SPLIT>
+__device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4 (&v)[4], long coff, int m, int n, int z1, int z2) {
+    constexpr bool wide_epi = EPI == kEpiNone || EPI == kEpiGelu || EPI == kEpiResidual || EPI == kEpiQkvScatter;
+    if (!wide_epi || n + 16 > p.N || (EPI == kEpiQkvScatter && n >= 2 * kHidden)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n + 4 * j < p.N) split_gemm_store<EPI, OUT_SPLIT>(p, v[j], coff, m, n + 4 * j, z1, z2);
+        return;
+    }
+    if (EPI == kEpiGelu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+    }
+    if (EPI == kEpiResidual) {
+        const float* rp = p.R + coff + (long)m * p.ldr + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += *reinterpret_cast<const f32x4*>(rp + 4 * j);
+    }
+    if (!OUT_SPLIT && EPI != kEpiQkvScatter) {
+        float* cp = p.C + coff + (long)m * p.ldc + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cp + 4 * j) = v[j];
+        return;
+    }
+    h8 hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[j][e];
+            asm volatile("" : "+v"(x));  // see split_gemm_store: keep hi and lo derived from the same rounded fp32 value
+            const _Float16 a = (_Float16)x;
+            hi[j >> 1][4 * (j & 1) + e] = a;
+            lo[j >> 1][4 * (j & 1) + e] = (_Float16)(x - (float)a);
+        }
+    _Float16 *dh, *dl;
+    if (EPI == kEpiQkvScatter) {
+        const bool isq = n < kHidden;
+        const long o = (long)m * kHidden + (isq ? n : n - kHidden);
+        dh = (isq ? p.Chi : p.Khi) + o;
+        dl = (isq ? p.Clo : p.Klo) + o;
+    } else {
+        const long o = coff + (long)m * p.ldc + n;
+        dh = p.Chi + o;
+        dl = p.Clo + o;
+    }
+    *reinterpret_cast<h8*>(dh) = hi[0];
+    *reinterpret_cast<h8*>(dh + 8) = hi[1];
+    *reinterpret_cast<h8*>(dl) = lo[0];
+    *reinterpret_cast<h8*>(dl + 8) = lo[1];
+}
+
 constexpr int SBK = 32;
 constexpr int SLD = SBK + 8;  // halves per LDS row (80 bytes)
 
@@ -273,6 +330,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     static_assert(NDA >= 1, "tile too small for the wave count");
     static_assert(WPIECES % NW_ == 0 || DSTAGES == 2, "uneven W pieces need the 2-stage ring (vmcnt(0) waits only)");
     static_assert(NJ == 4 || MF16, "NJ < 4 is implemented for the 16x16x32 path");
+    // PERMW: the 16 W rows (output columns) fed to MFMA sub-tile j are {16 q + 4 j + e}, q, e = 0..3, instead of 16 j .. 16 j + 15.
+    // The accumulator of lane quad q4 then holds columns 16 q4 + 4 j + e: over j = 0..3 one lane owns 16 CONSECUTIVE
+    // columns of its row, which the epilogue writes as 16-byte pieces (split_gemm_store16).  Same FLOPs and LDS bytes;
+    // only the fragment row of a lane and the W swizzle (piece ^ f((row >> 4) & 3), f = 0,2,3,1) change.  Used for fp16
+    // plane outputs (-4..9 % time on FFN1 / conv layers); fp32 outputs keep the plain mapping, whose 16-byte pieces of
+    // four neighbouring lanes already form 64-byte runs (the permuted form measured 4..15 % slower there).
+    constexpr bool PERMW = MF16 && NJ == 4 && (OUT_SPLIT || EPI == kEpiQkvScatter);
     __shared__ __attribute__((aligned(16))) _Float16 lds[DSTAGES * DBUF];
 
     int mt, nt, z;
@@ -312,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
         const int row = 16 * (NDW * wave + u) + drow;
         int rw = n0 + row;
         rw = rw < p.N ? rw : p.N - 1;
-        gw[u] = woff + (long)rw * p.ldw + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
+        gw[u] = woff + (long)rw * p.ldw + 8 * (dpos ^ (PERMW ? ((0x78 >> (2 * ((row >> 4) & 3))) & 3) : MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
     }
 #define DMA_ISSUE(kt, stage)                                                                                              \
     {                                                                                                                     \
@@ -364,7 +428,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     const int r16 = lane & 15, q4 = lane >> 4;
     const int swz = MF16 ? 3 * ((r16 >> 2) & 1) : ((r >> 2) & 3);
     const int fa = MF16 ? (wm * 64 + r16) * SBK + 8 * (q4 ^ swz) : (wm * 64 + r) * SBK;
-    const int fw = MF16 ? (wn * 64 + r16) * SBK + 8 * (q4 ^ swz) : (wn * 64 + r) * SBK;
+    const int fw = PERMW  ? (wn * 64 + 16 * (r16 >> 2) + (r16 & 3)) * SBK + 8 * (q4 ^ ((0x78 >> (2 * (r16 >> 2))) & 3))
+                   : MF16 ? (wn * 64 + r16) * SBK + 8 * (q4 ^ swz)
+                          : (wn * 64 + r) * SBK;
 #define DMA_FRAGS(b_, ks, F)                                                                          \
     {                                                                                                 \
         const int po_ = 8 * ((2 * (ks) + h) ^ swz);                                                   \
@@ -400,8 +466,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + 16 * j * SBK);
-                wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + 16 * j * SBK);
+                wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + (PERMW ? 4 : 16) * j * SBK);
+                wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + (PERMW ? 4 : 16) * j * SBK);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -432,6 +498,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
 #undef DMA_ISSUE
 #undef DMA_WAIT_PENDING
 
+    if (PERMW) {
+        // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 q4 + 4 j + e]
+        const int n = n0 + wn * 64 + 16 * q4;
+        if (n >= p.N) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + 16 * i + r16;
+            if (m >= p.M) continue;
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc16[i][j];
+                if (p.bias && n + 4 * j < p.N) v[j] += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n + 4 * j);
+            }
+            split_gemm_store16<EPI, OUT_SPLIT>(p, v, coff, m, n, z1, z2);
+        }
+        return;
+    }
     if (MF16) {
         // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
 #pragma unroll

@@ -5,9 +5,21 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("loco-asr_amd._lib")
 lib = L.load()
+libs = {"main": lib}
+for a in sys.argv[1:]:
+    if a.endswith(".so"):  # A/B another build inside the same process (same device, same clocks)
+        alt = C.CDLL(os.path.abspath(a))
+        alt.loco_op_gemm_f16x3.restype = lib.loco_op_gemm_f16x3.restype
+        alt.loco_op_gemm_f16x3.argtypes = lib.loco_op_gemm_f16x3.argtypes
+        libs["alt"] = alt
 M = 47968
 shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
           ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True)]
+if "--epi-study" in sys.argv:  # what the epilogue and the short K loop cost on the FFN1 / QKV shapes
+    shapes = [("ffn1", M, 3072, 768, 1, True), ("ffn1_noepi", M, 3072, 768, 0, True), ("ffn1_f32out", M, 3072, 768, 0, False),
+              ("ffn1_k1536", M, 3072, 1536, 0, False), ("ffn1_k3072", M, 3072, 3072, 0, False),
+              ("ffn2", M, 768, 3072, 2, False), ("ffn2_noepi", M, 768, 3072, 0, False), ("n768_k768", M, 768, 768, 0, False),
+              ("n1024_k768", M, 1024, 768, 0, False), ("n1536_k768", M, 1536, 768, 0, False)]
 torch.manual_seed(0)
 bufs = {}
 for name, m, n, k, epi, osplit in shapes:
@@ -20,21 +32,23 @@ for name, m, n, k, epi, osplit in shapes:
     b = torch.randn(n, device="cuda"); R = torch.randn(nb * m, n, device="cuda")
     Cc = torch.empty(nb * m, n, device="cuda"); chi = torch.empty(nb * m, n, device="cuda", dtype=torch.float16); clo = torch.empty_like(chi)
     bufs[name] = (ahi, alo, whi, wlo, b, R, Cc, chi, clo, nb)
-def run(name, m, n, k, epi, osplit):
+def run(name, m, n, k, epi, osplit, lb=lib):
     ahi, alo, whi, wlo, b, R, Cc, chi, clo, nb = bufs[name]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     conv = name.startswith("conv")
-    L.check(lib.loco_op_gemm_f16x3(ahi.data_ptr(), alo.data_ptr(), 2 * 512 if conv else k, whi.data_ptr(), wlo.data_ptr(), k,
+    L.check(lb.loco_op_gemm_f16x3(ahi.data_ptr(), alo.data_ptr(), 2 * 512 if conv else k, whi.data_ptr(), wlo.data_ptr(), k,
                                    None if conv else b.data_ptr(), R.data_ptr() if epi == 2 else None, n,
                                    None if osplit else Cc.data_ptr(), chi.data_ptr() if osplit else None, clo.data_ptr() if osplit else None, n,
                                    m, n, k, epi, nb, 1, (2 * m) * 512 if conv else 0, 0, m * n if conv else 0, 0, st))
-res = {s[0]: [] for s in shapes}
+res = {(v, s[0]): [] for s in shapes for v in libs}
 for rnd in range(6):
     for s in shapes:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        run(*s); e0.record(); run(*s); run(*s); e1.record(); torch.cuda.synchronize()
-        if rnd: res[s[0]].append(e0.elapsed_time(e1) / 2)
+        for v, lb in libs.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(*s, lb=lb); e0.record(); run(*s, lb=lb); run(*s, lb=lb); e1.record(); torch.cuda.synchronize()
+            if rnd: res[(v, s[0])].append(e0.elapsed_time(e1) / 2)
 for name, m, n, k, epi, osplit in shapes:
     nb = bufs[name][9]
-    t = sorted(res[name])[len(res[name]) // 2]
-    print(f"{name:9s} M={nb*m:8d} N={n:5d} K={k:5d} epi={epi} split_out={int(osplit)} {t:8.3f} ms  {2.0*nb*m*n*k/t/1e9:7.1f} TFLOP/s (algorithmic)")
+    for v in libs:
+        t = sorted(res[(v, name)])[len(res[(v, name)]) // 2]
+        print(f"{v:4s} {name:11s} M={nb*m:8d} N={n:5d} K={k:5d} epi={epi} split_out={int(osplit)} {t:8.3f} ms  {2.0*nb*m*n*k/t/1e9:7.1f} TFLOP/s (algorithmic)")
