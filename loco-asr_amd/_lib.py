@@ -45,6 +45,7 @@ SIGNATURES = {
     "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
     "loco_set_precision": (C.c_int, [_vp, C.c_int]),
     "loco_get_precision": (C.c_int, [_vp]),
+    "loco_set_streams": (C.c_int, [_vp, C.c_int]),
     "loco_set_taps": (C.c_int, [_vp, _vp, _vp, _vp]),
     "loco_set_profiling": (C.c_int, [_vp, C.c_int]),
     "loco_profile_reset": (C.c_int, [_vp]),

@@ -98,6 +98,10 @@ struct loco_encoder {
     bool sin_user = false;
     // taps
     float *tap_conv = nullptr, *tap_proj = nullptr, *tap_prenet = nullptr;
+    // concurrency: a batch may run as two half-batches on two streams (loco_set_streams)
+    int streams = 2;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // profiling
     bool profiling = false;
     std::vector<ProfRec> recs;
@@ -627,6 +631,11 @@ void loco_destroy(loco_encoder* e) {
         free_split(l.s2);
     }
     (void)hipFree(e->sin_tab);
+    if (e->side) {
+        (void)hipStreamDestroy(e->side);
+        (void)hipEventDestroy(e->ev_fork);
+        (void)hipEventDestroy(e->ev_join);
+    }
     for (auto& r : e->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -756,10 +765,29 @@ int64_t loco_output_frames(int64_t n) {
     return n;
 }
 
+namespace {
+// Two half-batches on two streams: clips are independent, so the halves give the same bits as one pass, and the tail of
+// every kernel of one half (the last, partly filled round of workgroups: up to 12 % of the N = 768 GEMMs) is filled by
+// the other half's kernels.  Worth it only while each half still fills the chip for several rounds per kernel.
+bool split_batch(const loco_encoder* e, int B, long L, Plan& p0, Plan& p1) {
+    if (e->streams < 2 || B < 2) return false;
+    const int B0 = (B + 1) / 2;
+    if (!make_plan(e, B0, L, p0) || !make_plan(e, B - B0, L, p1)) return false;
+    return p1.M >= 16384;
+}
+}  // namespace
+
 size_t loco_workspace_bytes(const loco_encoder* e, int32_t B, int64_t L) {
-    Plan p;
+    Plan p, p0, p1;
     if (!e || !make_plan(e, B, L, p)) return 0;
+    if (split_batch(e, B, L, p0, p1)) return std::max(p.total, p0.total + p1.total);
     return p.total;
+}
+
+int loco_set_streams(loco_encoder* e, int n) {
+    if (!e || (n != 1 && n != 2)) return fail(LOCO_E_INVALID, "loco_set_streams: n must be 1 or 2");
+    e->streams = n;
+    return LOCO_OK;
 }
 
 int loco_set_precision(loco_encoder* e, int mode) {
@@ -778,24 +806,9 @@ int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection,
     return LOCO_OK;
 }
 
-int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
-                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!e || !wav || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward: null argument");
-    if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
-    Plan p;
-    if (!make_plan(e, B, L, p))
-        return fail(LOCO_E_INVALID, "loco_forward: batch %d x %lld samples gives no output frame (need >= 400 samples)", B, (long long)L);
-    if (B > 65535) return fail(LOCO_E_INVALID, "loco_forward: batch %d > 65535", B);
-    if (p.M > 0x7fffffffL / 8) return fail(LOCO_E_INVALID, "loco_forward: B*T = %ld frames is too large", p.M);
-    if (workspace_bytes < p.total)
-        return fail(LOCO_E_WORKSPACE, "loco_forward: workspace %zu < required %zu bytes", workspace_bytes, p.total);
-    if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(wav) & 3))
-        return fail(LOCO_E_INVALID, "loco_forward: workspace must be 256-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
-    int rc = ensure_sin_rows(e, (int)p.T + 2, s);
-    if (rc) return rc;
-
-    char* ws = reinterpret_cast<char*>(workspace);
+namespace {
+int forward_one(loco_encoder* e, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
+                float* const* hidden_states, char* ws, hipStream_t s) {
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* bufA = reinterpret_cast<float*>(ws + p.off_a);
     float* bufB = reinterpret_cast<float*>(ws + p.off_b);
@@ -817,6 +830,45 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
     return e->precision == 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
+}
+}  // namespace
+
+int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
+                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !wav || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward: null argument");
+    if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
+    Plan p, p0, p1;
+    if (!make_plan(e, B, L, p))
+        return fail(LOCO_E_INVALID, "loco_forward: batch %d x %lld samples gives no output frame (need >= 400 samples)", B, (long long)L);
+    if (B > 65535) return fail(LOCO_E_INVALID, "loco_forward: batch %d > 65535", B);
+    if (p.M > 0x7fffffffL / 8) return fail(LOCO_E_INVALID, "loco_forward: B*T = %ld frames is too large", p.M);
+    // per-kernel timing, hidden-state and tap outputs keep the single in-order pass
+    const bool dual = !e->profiling && !hidden_states && !e->tap_conv && !e->tap_proj && !e->tap_prenet && split_batch(e, B, L, p0, p1);
+    const size_t need = dual ? p0.total + p1.total : p.total;
+    if (workspace_bytes < need)
+        return fail(LOCO_E_WORKSPACE, "loco_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(wav) & 3))
+        return fail(LOCO_E_INVALID, "loco_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_sin_rows(e, (int)p.T + 2, s);
+    if (rc) return rc;
+    char* ws = reinterpret_cast<char*>(workspace);
+    if (!dual) return forward_one(e, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
+
+    if (!e->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    }
+    const int B0 = (B + 1) / 2, B1 = B - B0;
+    HIP_TRY(hipEventRecord(e->ev_fork, s));  // the side stream starts after everything already queued on the caller's stream
+    HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    rc = forward_one(e, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
+    const int rc1 = forward_one(e, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
+                                out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
+    HIP_TRY(hipEventRecord(e->ev_join, e->side));  // ... and the caller's stream continues after both halves
+    HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    return rc ? rc : rc1;
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------

@@ -209,3 +209,41 @@ def test_hipgraph_replay_matches_eager_and_is_faster_for_one_utterance():
         assert tg < te * 1.25  # this shape turns out to be bound by per-workgroup latency of tiny grids, not by launches
     finally:
         enc.use_graphs = False
+
+
+def test_two_stream_half_batches_are_bit_identical():
+    """loco_set_streams(2): a large batch runs as two half-batches on two HIP streams (fork/join with events).  Clips are
+    independent, so the result must equal the single-stream pass bit for bit -- ragged lengths, odd batch size, consecutive
+    calls that reuse the workspace, and hipGraph capture of the fork/join included."""
+    m, _ = model(layers=2)
+    enc = m.speecht5.encoder
+    lens = [480000 - 1731 * i for i in range(23)]  # 23 clips of ~30 s: 12 + 11, each half >= 16384 frames
+    x, msk = la.synth.batch(lens)
+    xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
+    enc.streams = 1
+    one = enc(input_values=xs, attention_mask=ms).last_hidden_state
+    frames_one = enc.last_frames.clone() if getattr(enc, "last_frames", None) is not None else None
+    enc.streams = 2
+    try:
+        two = enc(input_values=xs, attention_mask=ms).last_hidden_state
+        assert torch.equal(one, two)
+        # the caller's stream must see the join: a kernel queued right after reads finished data
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            three = enc(input_values=xs, attention_mask=ms).last_hidden_state
+            chk = three.sum()
+        s.synchronize()
+        assert torch.equal(three, one) and float(chk) == float(one.sum())
+        nomask = enc(input_values=xs).last_hidden_state
+        enc.streams = 1
+        assert torch.equal(nomask, enc(input_values=xs).last_hidden_state)
+        enc.streams = 2
+        enc.use_graphs = True
+        a = enc(input_values=xs, attention_mask=ms).last_hidden_state  # capture
+        b = enc(input_values=xs, attention_mask=ms).last_hidden_state  # replay
+        assert torch.equal(a, one) and torch.equal(b, one)
+        if frames_one is not None:
+            assert torch.equal(enc.last_frames, frames_one)
+    finally:
+        enc.use_graphs = False
+        enc.streams = 2
