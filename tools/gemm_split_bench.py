@@ -14,7 +14,8 @@ for a in sys.argv[1:]:
         libs["alt"] = alt
 M = 47968
 shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
-          ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True)]
+          ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True),
+          ("qp", 1499, 320, 64, 0, False)]  # Qp[b,h] = q[b,:,h,:] pe_k^T: batched over 32 clips x 12 heads, A row stride 768
 if "--epi-study" in sys.argv:  # what the epilogue and the short K loop cost on the FFN1 / QKV shapes
     shapes = [("ffn1", M, 3072, 768, 1, True), ("ffn1_noepi", M, 3072, 768, 0, True), ("ffn1_f32out", M, 3072, 768, 0, False),
               ("ffn1_k1536", M, 3072, 1536, 0, False), ("ffn1_k3072", M, 3072, 3072, 0, False),
@@ -23,6 +24,11 @@ if "--epi-study" in sys.argv:  # what the epilogue and the short K loop cost on 
 torch.manual_seed(0)
 bufs = {}
 for name, m, n, k, epi, osplit in shapes:
+    if name == "qp":
+        ahi = torch.randn(32 * m, 768, device="cuda").half(); alo = (torch.randn(32 * m, 768, device="cuda") * 1e-3).half()
+        whi = (torch.randn(n, k, device="cuda") * 0.3).half(); wlo = (torch.randn(n, k, device="cuda") * 3e-4).half()
+        bufs[name] = (ahi, alo, whi, wlo, None, None, torch.empty(32 * 12 * m, n, device="cuda"), None, None, 32 * 12)
+        continue
     conv = name.startswith("conv")
     nb = 32 if conv else 1
     rows = nb * m * 2 + 8 if conv else m
@@ -35,6 +41,10 @@ for name, m, n, k, epi, osplit in shapes:
 def run(name, m, n, k, epi, osplit, lb=lib):
     ahi, alo, whi, wlo, b, R, Cc, chi, clo, nb = bufs[name]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if name == "qp":
+        L.check(lb.loco_op_gemm_f16x3(ahi.data_ptr(), alo.data_ptr(), 768, whi.data_ptr(), wlo.data_ptr(), k, None, None, 0, Cc.data_ptr(), None, None, n,
+                                      m, n, k, 0, 32, 12, m * 768, 64, 12 * m * n, m * n, st))
+        return
     conv = name.startswith("conv")
     L.check(lb.loco_op_gemm_f16x3(ahi.data_ptr(), alo.data_ptr(), 2 * 512 if conv else k, whi.data_ptr(), wlo.data_ptr(), k,
                                    None if conv else b.data_ptr(), R.data_ptr() if epi == 2 else None, n,
