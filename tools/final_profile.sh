@@ -1,0 +1,21 @@
+#!/bin/bash
+# End-of-round evidence run (on the GPU box, from the repo root): bench lines, rocprofv3 kernel stats of the same
+# command, and the PMC passes (one counter set per pass, --kernel-trace only) that profiles/ summarises.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/final
+rm -rf $O && mkdir -p $O
+python3 bench.py > $O/bench_30sx32.json 2> $O/bench_30sx32.err || exit 1
+echo "bench 30sx32 done" && tail -c 400 $O/bench_30sx32.json
+python3 bench.py --clip-seconds 600 --batch 4 --steps 3 --warmup 1 --no-cpu-baseline --no-alt > $O/bench_10minx4.json 2> $O/bench_10minx4.err || exit 1
+echo "bench 10minx4 done"
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 5 --no-cpu-baseline --no-alt --no-two-streams > $O/stats.log 2>&1 || exit 1
+echo "stats done"
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams > $O/pmc_$n.log 2>&1 || exit 1
+  python3 tools/pmc_summary.py "$O/pmc_$n/*/*counter_collection.csv" > $O/pmc_${n}_summary.txt
+  echo "pmc $n done"
+done
+python3 tools/pmc_traffic.py gemm_f16x3_dma_kernel $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv) $O/gemm_f16x3_traffic.json
+cp $(ls $O/stats/*/*kernel_stats.csv) $O/kernel_stats.csv
