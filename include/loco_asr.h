@@ -109,6 +109,24 @@ int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_m
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* ---- text front end ("next" row f-4): SpeechT5EncoderWithTextPrenet ---------------------------------------------
+ * The reference's text branch (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:79-93) runs
+ * `model.speecht5.encoder(texts.input_ids)`: SpeechT5TextEncoderPrenet (HF modeling_speecht5.py: embed_tokens +
+ * SpeechT5ScaledPositionalEncoding, x + alpha * pe[:T]) followed by the SAME 12-layer wrapped_encoder as the speech path.
+ * Weights: loco_set_weight keys "text_prenet.embed_tokens.weight" [vocab,768], "text_prenet.encode_positions.alpha" (one
+ * element, shape [1]) and optionally "text_prenet.encode_positions.pe" ([rows,768] or [1,rows,768]: HF's table, so that
+ * positions are bit-identical; without it the library generates 1024 rows).  A handle may carry the speech prenet, the
+ * text prenet, or both; loco_missing_weights does not ask for the speech prenet of a text-only handle.
+ *   input_ids      [B, T] int32 token ids in [0, vocab) (device)
+ *   attention_mask [B, T] int32 1 = token, 0 = right padding, or NULL (the reference passes none: pads attend like tokens)
+ *   out            [B, T, 768] fp32; out_frames [B] (valid tokens) or NULL; hidden_states as loco_forward
+ *   T <= loco_text_max_positions(enc) (HF: max_text_positions) */
+size_t loco_text_workspace_bytes(const loco_encoder* enc, int32_t B, int32_t T);
+int loco_text_max_positions(const loco_encoder* enc);
+int loco_forward_text(loco_encoder* enc, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T,
+                      float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* Arithmetic of the contractions (conv layers 1-6, feature projection, QKV / out / FFN projections, Qp table, QK^T, PV):
  *   1  "f16x3" (default): operands split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 per product, fp32
  *      accumulate; fp32-class accuracy (embeddings 3.5e-6 relative L2 of an fp64 evaluation) at 2x the speed of mode 0

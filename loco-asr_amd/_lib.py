@@ -43,6 +43,9 @@ SIGNATURES = {
     "loco_output_frames": (_i64, [_i64]),
     "loco_workspace_bytes": (_sz, [_vp, _i32, _i64]),
     "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_text_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "loco_text_max_positions": (C.c_int, [_vp]),
+    "loco_forward_text": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
     "loco_set_precision": (C.c_int, [_vp, C.c_int]),
     "loco_get_precision": (C.c_int, [_vp]),
     "loco_set_streams": (C.c_int, [_vp, C.c_int]),

@@ -98,6 +98,13 @@ struct loco_encoder {
     bool sin_user = false;
     // taps
     float *tap_conv = nullptr, *tap_proj = nullptr, *tap_prenet = nullptr;
+    // text front end (SpeechT5TextEncoderPrenet): optional; a handle may carry the speech prenet, the text prenet or both
+    float* text_embed = nullptr;  // [text_vocab, 768]
+    int text_vocab = 0;
+    float* text_alpha = nullptr;  // [1]
+    float* text_pe = nullptr;     // [text_pe_rows, 768]
+    int text_pe_rows = 0;
+    bool speech_ready = false;    // set by loco_finalize_weights when the speech prenet weights were supplied
     // concurrency: a batch may run as two half-batches on two streams (loco_set_streams)
     int streams = 2;
     hipStream_t side = nullptr;
@@ -173,6 +180,8 @@ struct Plan {
     size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1, total;
 };
 
+void carve_plan(const loco_encoder* e, Plan& p);
+
 bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     p.B = B;
     p.L = L;
@@ -184,6 +193,24 @@ bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     if (B <= 0 || n <= 0) return false;
     p.T = n;
     p.M = (long)B * n;
+    carve_plan(e, p);
+    return true;
+}
+
+// the text front end enters the encoder with T tokens per sequence: no waveform, no conv buffers
+bool make_plan_tokens(const loco_encoder* e, int B, long T, Plan& p) {
+    p.B = B;
+    p.L = 0;
+    for (int i = 0; i < 7; ++i) p.Tc[i] = 0;
+    if (B <= 0 || T <= 0) return false;
+    p.T = T;
+    p.M = (long)B * T;
+    carve_plan(e, p);
+    return true;
+}
+
+void carve_plan(const loco_encoder* e, Plan& p) {
+    const int B = p.B;
     const size_t f = sizeof(float);
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -209,7 +236,6 @@ bool make_plan(const loco_encoder* e, int B, long L, Plan& p) {
     p.off_xs0 = take((size_t)p.M * kHidden * f);  // fp16 hi|lo planes of x0 / x1 (precision f16x3)
     p.off_xs1 = take((size_t)p.M * kHidden * f);
     p.total = o;
-    return true;
 }
 
 // ---- profiling brackets -----------------------------------------------------------------------------
@@ -316,8 +342,9 @@ struct Bufs {
 };
 
 // ---- precision 0: every contraction on the exact-fp32 MFMA ------------------------------------------------------
+// skip_prenet: x0 already holds the encoder's input hidden states (the text front end wrote them)
 int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
-                hipStream_t s) {
+                hipStream_t s, bool skip_prenet = false) {
     const int B = p.B;
     const long L = p.L;
     const int T = (int)p.T;
@@ -327,6 +354,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
           *ffn = bf.ffn;
     const int32_t* frames_or_null = bf.frames_or_null;
     const std::string pn = "prenet.", we = "wrapped_encoder.";
+    if (!skip_prenet) {
     // ---- feature encoder (HF :484-494)
     {
         const double outb = 4.0 * B * (double)p.Tc[0] * kConvDim;
@@ -366,6 +394,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
         HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
+    }  // !skip_prenet
 
     // ---- encoder (HF :1276-1304)
     if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden))) return rc;
@@ -415,7 +444,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
 // exists.  conv0, the positional conv, the Qp table and attention stay on their fp32 kernels; residuals, LayerNorm
 // statistics and softmax stay fp32.
 int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
-                  hipStream_t s) {
+                  hipStream_t s, bool skip_prenet = false) {
     const int B = p.B;
     const long L = p.L;
     const int T = (int)p.T;
@@ -443,6 +472,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         lo = hi + n;
     };
 
+    if (!skip_prenet) {
     // ---- feature encoder: conv0 writes planes, conv1-5 planes -> planes, conv6 planes -> fp32 (LayerNorm input)
     _Float16 *ihi, *ilo, *ohi, *olo;
     planes(bf.bufA, (size_t)B * p.Tc[0] * kConvDim, ihi, ilo);
@@ -507,6 +537,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         HIP_TRY(launch_gemm_split(a, s));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
+    }  // !skip_prenet
 
     // ---- encoder
     _Float16 *x0hi = bf.xs0, *x0lo = bf.xs0 + (size_t)M * kHidden;
@@ -631,6 +662,9 @@ void loco_destroy(loco_encoder* e) {
         free_split(l.s2);
     }
     (void)hipFree(e->sin_tab);
+    (void)hipFree(e->text_embed);
+    (void)hipFree(e->text_alpha);
+    (void)hipFree(e->text_pe);
     if (e->side) {
         (void)hipStreamDestroy(e->side);
         (void)hipEventDestroy(e->ev_fork);
@@ -661,6 +695,33 @@ int loco_set_weight(loco_encoder* e, const char* key, const float* data, const i
         e->sin_user = true;
         return LOCO_OK;
     }
+    if (k.rfind("text_prenet.", 0) == 0) {
+        // SpeechT5TextEncoderPrenet.state_dict(): embed_tokens.weight [V,768], encode_positions.alpha [] (pass as [1]);
+        // encode_positions.pe [1,rows,768] or [rows,768] is a non-persistent buffer in current HF, a key in 4.30's pickles
+        float** slot = nullptr;
+        if (k == "text_prenet.embed_tokens.weight") {
+            if (ndim != 2 || shp[1] != kHidden || shp[0] < 1) return fail(LOCO_E_INVALID, "%s: expected [vocab,768]", key);
+            slot = &e->text_embed;
+            e->text_vocab = (int)shp[0];
+        } else if (k == "text_prenet.encode_positions.alpha") {
+            if (n != 1) return fail(LOCO_E_INVALID, "%s: expected one element", key);
+            slot = &e->text_alpha;
+        } else if (k == "text_prenet.encode_positions.pe") {
+            if (!((ndim == 2 && shp[1] == kHidden) || (ndim == 3 && shp[0] == 1 && shp[2] == kHidden)))
+                return fail(LOCO_E_INVALID, "%s: expected [rows,768] or [1,rows,768]", key);
+            slot = &e->text_pe;
+            e->text_pe_rows = (int)(n / kHidden);
+        } else {
+            return fail(LOCO_E_INVALID, "unexpected key in state_dict: %s", key);
+        }
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)n * sizeof(float)));
+        HIP_TRY(hipMemcpy(d, data, (size_t)n * sizeof(float), hipMemcpyDefault));
+        HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(*slot);
+        *slot = d;
+        return LOCO_OK;
+    }
     auto it = e->expected.find(k);
     if (it == e->expected.end()) return fail(LOCO_E_INVALID, "unexpected key in state_dict: %s", key);
     if (it->second != shp) {
@@ -682,11 +743,19 @@ int loco_missing_weights(const loco_encoder* e, char* buf, size_t buflen) {
     if (!e) return fail(LOCO_E_INVALID, "null encoder");
     int missing = 0;
     std::string names;
+    bool any_speech = false;
+    for (auto& kv : e->raw) any_speech = any_speech || kv.first.rfind("prenet.", 0) == 0;
+    const bool text_only = e->text_embed && !any_speech;  // a text-encoder handle: the speech prenet is not required
     for (auto& kv : e->expected) {
         if (optional_key(kv.first) || e->raw.count(kv.first)) continue;
+        if (text_only && kv.first.rfind("prenet.", 0) == 0) continue;
         ++missing;
         if (!names.empty()) names += ",";
         names += kv.first;
+    }
+    if (e->text_embed && !e->text_alpha) {
+        ++missing;
+        names += (names.empty() ? "" : ",") + std::string("text_prenet.encode_positions.alpha");
     }
     if (buf && buflen) snprintf(buf, buflen, "%s", names.c_str());
     return missing;
@@ -699,18 +768,27 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     const int miss = loco_missing_weights(e, names, sizeof names);
     if (miss) return fail(LOCO_E_STATE, "%d weights missing: %s", miss, names);
     const std::string p = "prenet.", w = "wrapped_encoder.";
+    const bool speech = e->raw.count(p + "feature_encoder.conv_layers.0.conv.weight") != 0;
+    e->speech_ready = false;
+    if (e->text_embed && !e->text_pe) {  // C callers without HF's table: 1024 rows from the library's own generator
+        HIP_TRY(hipMalloc(&e->text_pe, (size_t)1024 * kHidden * sizeof(float)));
+        HIP_TRY(launch_text_pe_table(e->text_pe, 1024, s));
+        e->text_pe_rows = 1024;
+    }
     // conv layers 1..6: [512,512,k] -> [512, k*512]
-    for (int i = 1; i < 7; ++i) {
+    for (int i = 1; speech && i < 7; ++i) {
         const size_t n = (size_t)kConvDim * kConvDim * kConvK[i];
         if (!e->conv_w[i]) HIP_TRY(hipMalloc(&e->conv_w[i], n * sizeof(float)));
         HIP_TRY(launch_relayout_conv_weight(W(e, p + "feature_encoder.conv_layers." + std::to_string(i) + ".conv.weight"),
                                             e->conv_w[i], kConvDim, kConvDim, kConvK[i], s));
     }
-    e->conv_w[0] = e->raw.at(p + "feature_encoder.conv_layers.0.conv.weight").d;
-    // positional conv: fold weight-norm, lay out [group][tap][o][i]
-    if (!e->pos_w) HIP_TRY(hipMalloc(&e->pos_w, (size_t)kHidden * kPosCg * kPosK * sizeof(float)));
-    HIP_TRY(launch_fold_pos_conv(W(e, p + "pos_conv_embed.conv.parametrizations.weight.original0"),
-                                 W(e, p + "pos_conv_embed.conv.parametrizations.weight.original1"), e->pos_w, s));
+    if (speech) {
+        e->conv_w[0] = e->raw.at(p + "feature_encoder.conv_layers.0.conv.weight").d;
+        // positional conv: fold weight-norm, lay out [group][tap][o][i]
+        if (!e->pos_w) HIP_TRY(hipMalloc(&e->pos_w, (size_t)kHidden * kPosCg * kPosK * sizeof(float)));
+        HIP_TRY(launch_fold_pos_conv(W(e, p + "pos_conv_embed.conv.parametrizations.weight.original0"),
+                                     W(e, p + "pos_conv_embed.conv.parametrizations.weight.original1"), e->pos_w, s));
+    }
     // fused QKV with the 1/8 query scaling folded in: (x Wq^T + bq)/8 == x (Wq/8)^T + bq/8 exactly (power of two)
     const size_t hh = (size_t)kHidden * kHidden;
     for (int l = 0; l < e->cfg.layers; ++l) {
@@ -728,10 +806,10 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     // fp16 hi/lo planes of every GEMM weight for precision mode f16x3 (378 MB; built unconditionally so that the
     // mode can be switched per forward)
     int rc = LOCO_OK;
-    for (int i = 1; i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
-    if (!rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
+    for (int i = 1; speech && i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
+    if (speech && !rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
     if (!rc) rc = make_split(e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
-    if (!rc) {  // positional conv weight re-laid [g][o][tap*48+i] for the conv-as-GEMM form, then split
+    if (speech && !rc) {  // positional conv weight re-laid [g][o][tap*48+i] for the conv-as-GEMM form, then split
         float* tmpw = nullptr;
         const size_t n = (size_t)kHidden * kPosCg * kPosK;
         HIP_TRY(hipMalloc(&tmpw, n * sizeof(float)));
@@ -750,9 +828,12 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
         if (!rc) rc = make_split(lw.s2, W(e, b + "feed_forward.output_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
     }
     if (rc) return rc;
-    rc = ensure_sin_rows(e, 4002, s);
-    if (rc) return rc;
+    if (speech) {
+        rc = ensure_sin_rows(e, 4002, s);
+        if (rc) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(s));
+    e->speech_ready = speech;
     e->finalized = true;
     return LOCO_OK;
 }
@@ -837,6 +918,7 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
                  int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
     if (!e || !wav || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward: null argument");
     if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
+    if (!e->speech_ready) return fail(LOCO_E_STATE, "loco_forward: this encoder was loaded without the speech prenet weights");
     Plan p, p0, p1;
     if (!make_plan(e, B, L, p))
         return fail(LOCO_E_INVALID, "loco_forward: batch %d x %lld samples gives no output frame (need >= 400 samples)", B, (long long)L);
@@ -869,6 +951,51 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     HIP_TRY(hipEventRecord(e->ev_join, e->side));  // ... and the caller's stream continues after both halves
     HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
     return rc ? rc : rc1;
+}
+
+// ---- text front end ---------------------------------------------------------------------------------------
+size_t loco_text_workspace_bytes(const loco_encoder* e, int32_t B, int32_t T) {
+    Plan p;
+    if (!e || !make_plan_tokens(e, B, T, p)) return 0;
+    return p.total;
+}
+
+int loco_text_max_positions(const loco_encoder* e) { return e ? e->text_pe_rows : 0; }
+
+int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T, float* out,
+                      int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !input_ids || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward_text: null argument");
+    if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward_text: call loco_finalize_weights first");
+    if (!e->text_embed || !e->text_alpha || !e->text_pe)
+        return fail(LOCO_E_STATE, "loco_forward_text: this encoder was loaded without the text prenet weights");
+    Plan p;
+    if (!make_plan_tokens(e, B, T, p)) return fail(LOCO_E_INVALID, "loco_forward_text: batch %d x %d tokens is empty", B, T);
+    if (B > 65535) return fail(LOCO_E_INVALID, "loco_forward_text: batch %d > 65535", B);
+    if (T > e->text_pe_rows)
+        return fail(LOCO_E_INVALID, "loco_forward_text: %d tokens exceed the positional table (%d rows: max_text_positions)", T,
+                    e->text_pe_rows);
+    if (workspace_bytes < p.total)
+        return fail(LOCO_E_WORKSPACE, "loco_forward_text: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(LOCO_E_INVALID, "loco_forward_text: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = reinterpret_cast<char*>(workspace);
+    int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
+    float* x0 = reinterpret_cast<float*>(ws + p.off_x0);
+    {
+        Bracket br(e, s, K_FRAMES, 0.0, attention_mask ? 4.0 * B * (double)T : 0.0);
+        HIP_TRY(launch_token_counts(attention_mask, B, T, frames, s));
+    }
+    {   // embed_tokens + alpha * pe (HF SpeechT5TextEncoderPrenet.forward)
+        Bracket br(e, s, K_COPY, 0.0, 12.0 * p.M * kHidden);
+        HIP_TRY(launch_text_prenet(input_ids, e->text_embed, e->text_vocab, e->text_alpha, e->text_pe, B, T, x0, s));
+    }
+    struct Bufs bufs{frames, attention_mask ? frames : nullptr, reinterpret_cast<float*>(ws + p.off_a), reinterpret_cast<float*>(ws + p.off_b),
+                     x0, reinterpret_cast<float*>(ws + p.off_x1), reinterpret_cast<float*>(ws + p.off_tmp),
+                     reinterpret_cast<float*>(ws + p.off_ctx), reinterpret_cast<float*>(ws + p.off_qkv),
+                     reinterpret_cast<float*>(ws + p.off_qp), reinterpret_cast<float*>(ws + p.off_ffn),
+                     reinterpret_cast<_Float16*>(ws + p.off_xs0), reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    return e->precision == 1 ? forward_f16x3(e, p, nullptr, out, hidden_states, bufs, s, true)
+                             : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------

@@ -100,6 +100,10 @@ hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w,
                                 float* out, void* scratch, float eps, hipStream_t s, void* out_hi = nullptr,
                                 void* out_lo = nullptr);
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
+hipError_t launch_token_counts(const int32_t* mask, int B, int T, int32_t* frames, hipStream_t s);
+hipError_t launch_text_prenet(const int32_t* ids, const float* embed, int vocab, const float* alpha, const float* pe, int B, int T,
+                              float* out, hipStream_t s);
+hipError_t launch_text_pe_table(float* pe, int rows, hipStream_t s);
 hipError_t launch_pos_conv(const float* h, const float* wf, const float* bias, const float* sin_table,
                            const int32_t* frames, float* out, int B, int T, hipStream_t s);
 hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,

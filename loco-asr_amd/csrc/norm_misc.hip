@@ -140,6 +140,76 @@ hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* fram
     return hipGetLastError();
 }
 
+// Token-level valid counts for the text front end: frames[b] = sum_t mask[b,t] (the encoder's key mask is a prefix mask:
+// the tokenizer pads on the right), or T without a mask.
+__global__ void token_counts_kernel(const int32_t* __restrict__ mask, int B, int T, int32_t* __restrict__ frames) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int n = T;
+    if (mask) {
+        n = 0;
+        for (int t = 0; t < T; ++t) n += mask[(long)b * T + t] != 0;
+    }
+    frames[b] = n;
+}
+
+hipError_t launch_token_counts(const int32_t* mask, int B, int T, int32_t* frames, hipStream_t s) {
+    if (B <= 0 || T <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(token_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, s, mask, B, T, frames);
+    return hipGetLastError();
+}
+
+// SpeechT5TextEncoderPrenet (HF modeling_speecht5.py: embed_tokens + SpeechT5ScaledPositionalEncoding):
+//   out[b,t,:] = embed[ids[b,t], :] + alpha * pe[t, :]          (dropout is the identity in eval)
+// one thread = 4 channels; ids outside [0, vocab) are clamped (the host wrapper rejects them, as nn.Embedding would).
+__global__ void text_prenet_kernel(const int32_t* __restrict__ ids, const float* __restrict__ embed, int vocab,
+                                   const float* __restrict__ alpha, const float* __restrict__ pe, int T, long n4,
+                                   float* __restrict__ out) {
+    const float a = alpha[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (kHidden / 4);
+        const int c4 = (int)(i - m * (kHidden / 4));
+        const int t = (int)(m % T);
+        int id = ids[m];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const f32x4 ev = reinterpret_cast<const f32x4*>(embed + (long)id * kHidden)[c4];
+        const f32x4 pv = reinterpret_cast<const f32x4*>(pe + (long)t * kHidden)[c4];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __fadd_rn(ev[e], __fmul_rn(a, pv[e]));  // HF: emb + (alpha * pe), two roundings: no FMA
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+hipError_t launch_text_prenet(const int32_t* ids, const float* embed, int vocab, const float* alpha, const float* pe, int B, int T,
+                              float* out, hipStream_t s) {
+    if (B <= 0 || T <= 0 || vocab <= 0) return hipErrorInvalidValue;
+    const long n4 = (long)B * T * (kHidden / 4);
+    const long blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(text_prenet_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, s, ids, embed, vocab, alpha, pe, T,
+                       n4, out);
+    return hipGetLastError();
+}
+
+// The library's own table for C callers (the Python host uploads the table computed with HF's torch expression):
+// pe[p, 2k] = sin(p * w_k), pe[p, 2k+1] = cos(p * w_k), w_k = exp(2k * -(ln 10000 / 768))
+__global__ void text_pe_table_kernel(float* __restrict__ pe, int rows) {
+    const long total = (long)rows * (kHidden / 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % (kHidden / 2));
+        const int pos = (int)(i / (kHidden / 2));
+        const float w = expf((float)(2 * k) * -(logf(10000.0f) / (float)kHidden));
+        const float ang = (float)pos * w;
+        pe[(long)pos * kHidden + 2 * k] = sinf(ang);
+        pe[(long)pos * kHidden + 2 * k + 1] = cosf(ang);
+    }
+}
+
+hipError_t launch_text_pe_table(float* pe, int rows, hipStream_t s) {
+    hipLaunchKernelGGL(text_pe_table_kernel, dim3(256), dim3(256), 0, s, pe, rows);
+    return hipGetLastError();
+}
+
 // Conv1d weight [N, C, k] -> tap-major [N, k*C] so that a channels-last input row run is the GEMM's A row.
 __global__ void relayout_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int C, int k) {
     const long total = (long)N * C * k;

@@ -210,7 +210,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
     def _ensure_handle(self, device: torch.device):
         if device.type != "cuda":
             raise RuntimeError(
-                "SpeechT5EncoderWithSpeechPrenetMI355X runs only on an AMD GPU through its HIP kernels "
+                f"{type(self).__name__} runs only on an AMD GPU through its HIP kernels "
                 f"(got device {device}); move the module and its inputs with .to('cuda'). There is no CPU path.")
         if self._handle is not None and self._handle_device != device:
             self._lib.loco_destroy(self._handle)

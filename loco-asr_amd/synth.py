@@ -124,6 +124,31 @@ def encoder_state_dict(seed: int = 0, layers: int = LAYERS) -> dict[str, np.ndar
     return sd
 
 
+TEXT_VOCAB = 81          # SpeechT5Config.vocab_size
+MAX_TEXT_POSITIONS = 450  # SpeechT5Config.max_text_positions
+
+
+def text_prenet_state_dict(seed: int = 0) -> dict[str, np.ndarray]:
+    """Weights of SpeechT5TextEncoderPrenet under the prefix ``text_prenet.``: a non-trivial embedding table and a
+    positional scale alpha != 1 (HF initialises it to 1.0; a trained checkpoint does not keep it there)."""
+    p = "text_prenet."
+    return {p + "embed_tokens.weight": _w(p + "embed_tokens.weight", (TEXT_VOCAB, HIDDEN), 0.6, seed),
+            p + "encode_positions.alpha": np.asarray(1.37, dtype=np.float32)}
+
+
+def token_ids(batch: int, tokens: int, seed: int = 7, lengths=None):
+    """Deterministic synthetic token ids [batch, tokens] in [4, TEXT_VOCAB) (0..3 are the special tokens; 1 = <pad>) and the
+    int32 right-padding mask for ``lengths`` (pad id 1 beyond each length), mirroring ``processor(text=..., padding="longest")``."""
+    u = hashed_uniform(f"token_ids/{batch}x{tokens}", (batch, tokens), seed)
+    ids = (4 + np.floor((u + 1.0) * 0.5 * (TEXT_VOCAB - 4))).astype(np.int64).clip(4, TEXT_VOCAB - 1)
+    mask = np.ones((batch, tokens), dtype=np.int32)
+    if lengths is not None:
+        for i, n in enumerate(lengths):
+            ids[i, n:] = 1
+            mask[i, n:] = 0
+    return ids, mask
+
+
 def split_state_dict(sd: dict):
     """(prenet_sd, wrapped_encoder_sd) with the prefixes stripped -- the two dicts the
     reference loads separately (extract_speecht5_base_embeddings_slurp.py:99-100)."""

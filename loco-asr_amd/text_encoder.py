@@ -1,0 +1,180 @@
+"""Drop-in for the reference's TEXT branch: ``SpeechT5ForTextToSpeech(...).speecht5.encoder``.
+
+/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:79-93 loads a ``wrapped_encoder`` and a text
+``prenet`` state dict into HF's ``SpeechT5EncoderWithTextPrenet`` and calls ``model.speecht5.encoder(texts.input_ids)``
+-- token ids only, no attention mask -- keeping ``out.last_hidden_state``.  HF (modeling_speecht5.py,
+``SpeechT5TextEncoderPrenet`` / ``SpeechT5ScaledPositionalEncoding`` / ``SpeechT5EncoderWithTextPrenet``):
+``hidden = embed_tokens(ids) + alpha * pe[:, :T]`` followed by the same 12-layer encoder the speech path uses.
+
+The arithmetic runs in ``libloco_asr.so`` (``loco_forward_text``); this module only keeps HF's names and call contract.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib
+from .encoder import (HIDDEN, LAYERS, BaseModelOutput, SpeechT5EncoderMI355X, SpeechT5EncoderWithSpeechPrenetMI355X,
+                      _Ref, _SpeechT5Core, _WeightHolder)
+
+VOCAB_SIZE = 81           # SpeechT5Config.vocab_size
+MAX_TEXT_POSITIONS = 450  # SpeechT5Config.max_text_positions
+PAD_TOKEN_ID = 1
+
+
+def scaled_positional_table(rows: int, dim: int = HIDDEN) -> torch.Tensor:
+    """SpeechT5ScaledPositionalEncoding.__init__ -- the same torch expression, so the table is bit-identical to HF's."""
+    pe = torch.zeros(rows, dim)
+    position = torch.arange(0, rows).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.int64).float() * -(math.log(10000.0) / dim))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe
+
+
+class SpeechT5TextEncoderPrenetMI355X(_WeightHolder):
+    """Parameter names of HF SpeechT5TextEncoderPrenet: ``embed_tokens.weight`` [vocab,768], ``encode_positions.alpha`` []."""
+
+    def __init__(self, owner_ref, vocab_size: int = VOCAB_SIZE):
+        super().__init__(owner_ref)
+        emb = nn.Module()
+        emb.register_parameter("weight", nn.Parameter(torch.zeros(vocab_size, HIDDEN), requires_grad=False))
+        self.add_module("embed_tokens", emb)
+        pos = nn.Module()
+        pos.register_parameter("alpha", nn.Parameter(torch.tensor(1.0), requires_grad=False))
+        self.add_module("encode_positions", pos)
+
+    def _translate(self, sd):
+        # transformers 4.30.2 (the reference's pin) registers the table as a persistent buffer and the reference's pickled
+        # dict carries it (map_speecht5_hf.py:168-181); it is a constant of (max_len, dim) and is rebuilt here
+        sd.pop("encode_positions.pe", None)
+        return sd
+
+
+class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X):
+    """``forward(input_values=ids [B,T], attention_mask=None, ...) -> BaseModelOutput`` like HF's class of the same name."""
+
+    def __init__(self, layers: int = LAYERS, precision: str = "f16x3", vocab_size: int = VOCAB_SIZE,
+                 max_text_positions: int = MAX_TEXT_POSITIONS):
+        nn.Module.__init__(self)
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}")
+        self.precision = precision
+        self._lib = _lib.load()  # raises when the HIP library is missing: no fallback
+        ref = _Ref()
+        self.prenet = SpeechT5TextEncoderPrenetMI355X(ref, vocab_size)
+        self.wrapped_encoder = SpeechT5EncoderMI355X(ref, layers)
+        ref.obj = self
+        self.num_layers = layers
+        self.vocab_size = vocab_size
+        self.max_text_positions = max_text_positions
+        self._handle = None
+        self._handle_device = None
+        self._weights_dirty = True
+        self._workspace = None
+        self._sin_rows = 0
+        self._taps = None
+        self.use_graphs = False
+        self._graphs = {}
+        self.streams = 1
+        self.last_frames = None
+        self.eval()
+
+    def _sync_weights(self, device: torch.device, min_sin_rows: int = 0):
+        if not self._weights_dirty:
+            return
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+        def put(key, t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            if t.dim() == 0:
+                t = t.reshape(1)
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self._lib.loco_set_weight(self._handle, key.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()), "load_state_dict")
+
+        for name, p in self.prenet.state_dict().items():
+            put("text_prenet." + name, p)
+        put("text_prenet.encode_positions.pe", scaled_positional_table(self.max_text_positions))
+        for name, p in self.wrapped_encoder.state_dict().items():
+            put("wrapped_encoder." + name, p)
+        _lib.check(self._lib.loco_finalize_weights(self._handle, stream), "finalize_weights")
+        self._weights_dirty = False
+
+    def workspace_bytes(self, batch: int, tokens: int) -> int:
+        self._ensure_handle(self._device())
+        return int(self._lib.loco_text_workspace_bytes(self._handle, batch, tokens))
+
+    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
+                return_dict: Optional[bool] = None, **kwargs):
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        if output_attentions:
+            raise NotImplementedError("output_attentions=True: the flash-style attention kernel never forms the [T,T] weights")
+        ids = input_values
+        if ids.dim() != 2 or ids.dtype.is_floating_point or ids.dtype == torch.bool:
+            raise ValueError(f"input_values must be integer token ids [batch, tokens], got {ids.dtype} {tuple(ids.shape)}")
+        device = ids.device
+        self._ensure_handle(device)
+        if self._device() != device:
+            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
+        B, T = ids.shape
+        if T < 1 or B < 1:
+            raise ValueError("empty batch")
+        if T > self.max_text_positions:
+            raise ValueError(f"{T} tokens exceed max_text_positions = {self.max_text_positions}")
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= self.vocab_size:
+            raise IndexError(f"token id out of range [0, {self.vocab_size}): min {lo}, max {hi}")  # nn.Embedding raises IndexError too
+        ids32 = ids.to(torch.int32).contiguous()
+        m = None
+        if attention_mask is not None:
+            if attention_mask.shape != ids.shape:
+                raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(ids.shape)}")
+            m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+            if T > 1 and not bool((m[:, 1:] <= m[:, :-1]).all()):
+                raise NotImplementedError("attention_mask must be right padding (ones then zeros), as the tokenizer produces it")
+        with torch.cuda.device(device):
+            self._sync_weights(device)
+            _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
+            need = int(self._lib.loco_text_workspace_bytes(self._handle, B, T))
+            if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
+                self._workspace = None
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
+            out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+            frames = torch.empty((B,), dtype=torch.int32, device=device)
+            hs, hs_ptrs = None, None
+            if output_hidden_states:
+                hs = [torch.empty_like(out) for _ in range(self.num_layers + 1)]
+                hs_ptrs = (C.c_void_p * (self.num_layers + 1))(*[t.data_ptr() for t in hs])
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            _lib.check(self._lib.loco_forward_text(self._handle, C.c_void_p(ids32.data_ptr()),
+                                                   C.c_void_p(m.data_ptr()) if m is not None else None, B, T,
+                                                   C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
+                                                   C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream),
+                       "loco_forward_text")
+        self.last_frames = frames
+        hidden = tuple(hs) if hs is not None else None
+        if return_dict is False:
+            return tuple(v for v in (out, hidden) if v is not None)
+        return BaseModelOutput(last_hidden_state=out, hidden_states=hidden, attentions=None)
+
+
+class SpeechT5ForTextToSpeechMI355X(nn.Module):
+    """Only as much of HF's SpeechT5ForTextToSpeech as the reference touches: ``.speecht5.encoder`` (…base…py:80-86)."""
+
+    def __init__(self, layers: int = LAYERS, precision: str = "f16x3"):
+        super().__init__()
+        self.speecht5 = _SpeechT5Core(SpeechT5EncoderWithTextPrenetMI355X(layers, precision))
+        self.eval()
+
+    @classmethod
+    def from_state_dicts(cls, text_prenet_state_dict, encoder_state_dict, layers: int = LAYERS, precision: str = "f16x3"):
+        model = cls(layers, precision)
+        model.speecht5.encoder.wrapped_encoder.load_state_dict(encoder_state_dict)
+        model.speecht5.encoder.prenet.load_state_dict(text_prenet_state_dict)
+        return model

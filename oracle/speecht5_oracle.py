@@ -234,6 +234,41 @@ def encode(input_values, attention_mask, sd, dtype=torch.float32, q_block=512, t
     return wrapped_encoder(h, frames, sd, "wrapped_encoder.", dtype, q_block, hidden_states)
 
 
+def scaled_positional_table(n_rows, dim=768, dtype=torch.float32):
+    """SpeechT5ScaledPositionalEncoding.__init__ (HF modeling_speecht5.py, class SpeechT5ScaledPositionalEncoding):
+    pe[p, 0::2] = sin(p * w), pe[p, 1::2] = cos(p * w), w_k = exp(2k * -(ln 10000 / dim)); built in fp32 as HF does."""
+    pe = torch.zeros(n_rows, dim)
+    position = torch.arange(0, n_rows).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.int64).float() * -(math.log(10000.0) / dim))
+    pe[:, 0::2] = torch.sin(position.float() * div_term)
+    pe[:, 1::2] = torch.cos(position.float() * div_term)
+    return pe.to(dtype)
+
+
+def text_prenet(input_ids, sd, prefix="text_prenet.", dtype=torch.float32):
+    """SpeechT5TextEncoderPrenet.forward (HF modeling_speecht5.py: embed_tokens, then SpeechT5ScaledPositionalEncoding.forward:
+    emb + alpha * pe[:, :T]; dropout is the identity in eval).  ids [B,T] -> [B,T,768]."""
+    ids = torch.as_tensor(input_ids).long()
+    emb = _t(sd, prefix + "embed_tokens.weight", dtype)[ids]
+    alpha = _t(sd, prefix + "encode_positions.alpha", dtype).reshape(())
+    pe = scaled_positional_table(ids.shape[1], emb.shape[-1], dtype)
+    return emb + alpha * pe[None]
+
+
+@torch.no_grad()
+def encode_text(input_ids, attention_mask, sd, dtype=torch.float32, q_block=512, hidden_states=None):
+    """SpeechT5EncoderWithTextPrenet.forward (HF modeling_speecht5.py): text prenet, then the same wrapped encoder as the
+    speech path.  The reference calls it WITHOUT a mask (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:86:
+    pad tokens attend like any other token); with a mask (right padding) the keys beyond each row's token count are masked."""
+    h = text_prenet(input_ids, sd, "text_prenet.", dtype)
+    frames = None
+    if attention_mask is not None:
+        m = torch.as_tensor(attention_mask)
+        frames = m.long().sum(1)
+        assert bool((m[:, 1:] <= m[:, :-1]).all()), "the restatement covers right padding (prefix masks)"
+    return wrapped_encoder(h, frames, sd, "wrapped_encoder.", dtype, q_block, hidden_states)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Probe-row variants: the same maths restricted to a few output rows, so that 10-minute inputs (T = 29 999,
 # BASELINE.json configs[2]) can be checked in seconds.  They take the stage INPUT (as produced by the

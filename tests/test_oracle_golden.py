@@ -87,3 +87,38 @@ def test_frame_counts(oracle, synth):
     m[0, :1000] = 1
     m[1, :400] = 1
     assert oracle.frame_counts(m, 2).tolist() == [2, 1]
+
+
+def _text_sd(synth, state_dict):
+    sd = dict(state_dict)
+    sd.update(synth.text_prenet_state_dict(0))
+    return sd
+
+
+def test_g6_text_encoder_without_and_with_mask(oracle, synth, state_dict):
+    """"next" row f-4: SpeechT5EncoderWithTextPrenet as the reference's text branch calls it (ids only: pads attend), and
+    with the tokenizer's right-padding mask; plus a row of max_text_positions tokens."""
+    g = golden("g6_text.npz")
+    sd = _text_sd(synth, state_dict)
+    lengths = list(g["lengths"])
+    ids, mask = synth.token_ids(3, 57, lengths=lengths)
+    rows = g["short_rows"]
+    pre = oracle.text_prenet(ids, sd)
+    assert pre.shape == (3, 57, 768)
+    assert rel_l2(pre[:, rows], g["prenet"]) < 1e-7  # gather + one multiply-add: exact up to the last bit
+    hs = []
+    y = oracle.encode_text(ids, None, sd, hidden_states=hs)
+    assert rel_l2(y[:, rows], g["nomask_last"]) < TOL
+    assert len(hs) == 13
+    for i, h in enumerate(hs):
+        assert abs(float(h.double().norm()) / g["nomask_hidden_stats"][i, 0] - 1) < 1e-6, i
+    hs = []
+    ym = oracle.encode_text(ids, mask, sd, hidden_states=hs)
+    assert rel_l2(ym, g["masked_last"]) < TOL
+    for i, h in enumerate(hs):
+        assert abs(float(h.double().norm()) / g["masked_hidden_stats"][i, 0] - 1) < 1e-6, i
+    assert rel_l2(ym[1, :31], y[1, :31]) > 1e-3  # the mask matters: pads are keys for every row when it is absent
+    long_ids, _ = synth.token_ids(1, synth.MAX_TEXT_POSITIONS, seed=11)
+    yl = oracle.encode_text(long_ids, None, sd)
+    assert rel_l2(yl[:, g["long_rows"]], g["long_last"]) < TOL
+    assert abs(float(yl.double().norm()) / g["long_stats"][0] - 1) < 1e-6
