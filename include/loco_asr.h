@@ -109,6 +109,15 @@ int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_m
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* ---- waveform normaliser ("next" row f-4): SpeechT5FeatureExtractor(do_normalize=True) on the device -------------------
+ * HF feature_extraction_speecht5.py:119-138 (the reference's collate_fn reaches it through processor(audio=...),
+ * /root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:60): per clip, over its UNPADDED samples
+ * n = sum(attention_mask[b]) (all L when the mask is NULL), y = (x - mean) / sqrt(var + 1e-7) with the population
+ * variance; samples t >= n are set to padding_value.  fp64 moments in a fixed order (reproducible); out may alias wav. */
+size_t loco_normalize_scratch_bytes(int32_t B);
+int loco_op_normalize_waveform(const float* wav, const int32_t* attention_mask, int32_t B, int64_t L, float padding_value,
+                               float* out, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- text front end ("next" row f-4): SpeechT5EncoderWithTextPrenet ---------------------------------------------
  * The reference's text branch (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:79-93) runs
  * `model.speecht5.encoder(texts.input_ids)`: SpeechT5TextEncoderPrenet (HF modeling_speecht5.py: embed_tokens +

@@ -43,6 +43,8 @@ SIGNATURES = {
     "loco_output_frames": (_i64, [_i64]),
     "loco_workspace_bytes": (_sz, [_vp, _i32, _i64]),
     "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_normalize_scratch_bytes": (_sz, [_i32]),
+    "loco_op_normalize_waveform": (C.c_int, [_vp, _vp, _i32, _i64, C.c_float, _vp, _vp, _sz, _vp]),
     "loco_text_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "loco_text_max_positions": (C.c_int, [_vp]),
     "loco_forward_text": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),

@@ -1087,6 +1087,18 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
 
 int32_t loco_op_vt_column(int32_t t) { return loco::vt_col(t); }
 
+size_t loco_normalize_scratch_bytes(int32_t B) { return B > 0 ? normalize_scratch_bytes(B) : 0; }
+
+int loco_op_normalize_waveform(const float* wav, const int32_t* attention_mask, int32_t B, int64_t L, float padding_value, float* out,
+                               void* scratch, size_t scratch_bytes, void* stream) {
+    if (!wav || !out || !scratch || B <= 0 || L <= 0) return fail(LOCO_E_INVALID, "loco_op_normalize_waveform: null/invalid argument");
+    if (scratch_bytes < normalize_scratch_bytes(B) || (reinterpret_cast<uintptr_t>(scratch) & 7))
+        return fail(LOCO_E_WORKSPACE, "loco_op_normalize_waveform: scratch %zu < %zu bytes (or not 8-byte aligned)", scratch_bytes,
+                    normalize_scratch_bytes(B));
+    HIP_TRY(launch_normalize_waveform(wav, attention_mask, B, L, padding_value, out, scratch, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
 int loco_op_split_f16(const float* x, void* hi, void* lo, int64_t n, void* stream) {
     if (!x || !hi || !lo || n <= 0 || (n & 3)) return fail(LOCO_E_INVALID, "loco_op_split_f16: invalid argument");
     HIP_TRY(launch_split_f16(x, hi, lo, n, (hipStream_t)stream));

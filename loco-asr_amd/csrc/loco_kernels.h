@@ -100,6 +100,9 @@ hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w,
                                 float* out, void* scratch, float eps, hipStream_t s, void* out_hi = nullptr,
                                 void* out_lo = nullptr);
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
+size_t normalize_scratch_bytes(int B);
+hipError_t launch_normalize_waveform(const float* wav, const int32_t* mask, int B, long L, float pad, float* out, void* scratch,
+                                     hipStream_t s);
 hipError_t launch_token_counts(const int32_t* mask, int B, int T, int32_t* frames, hipStream_t s);
 hipError_t launch_text_prenet(const int32_t* ids, const float* embed, int vocab, const float* alpha, const float* pe, int B, int T,
                               float* out, hipStream_t s);

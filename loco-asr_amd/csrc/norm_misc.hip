@@ -140,6 +140,96 @@ hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* fram
     return hipGetLastError();
 }
 
+// ---- zero_mean_unit_var_norm on the device ("next" row f-4) -------------------------------------------------------
+// HF feature_extraction_speecht5.py:119-138 (do_normalize): per clip, over its n = sum(mask) UNPADDED samples,
+//   y[t] = (x[t] - mean) / sqrt(var + 1e-7)   for t < n   (population variance),   y[t] = padding_value   for t >= n.
+// Moments are accumulated in fp64 in a fixed order (thread-strided partial sums, a fixed shared-memory tree, then the
+// parts in sequence), so the result is bitwise reproducible; numpy's fp32 pairwise sums differ from it by ~1e-7 relative.
+constexpr int kNormParts = 128;
+
+__global__ __launch_bounds__(256) void wav_moments_kernel(const float* __restrict__ x, long L, const int32_t* __restrict__ counts,
+                                                          double* __restrict__ part) {
+    const int b = blockIdx.y;
+    const long n = counts ? counts[b] : L;
+    const long chunk = ((n + kNormParts - 1) / kNormParts + 3) & ~3L;
+    long i0 = (long)blockIdx.x * chunk, i1 = i0 + chunk;
+    i1 = i1 < n ? i1 : n;
+    const float* xb = x + (long)b * L;
+    double s = 0.0, q = 0.0;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double v = xb[i];
+        s += v;
+        q += v * v;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[((long)b * kNormParts + blockIdx.x) * 2] = sh[0][0];
+        part[((long)b * kNormParts + blockIdx.x) * 2 + 1] = sh[1][0];
+    }
+}
+
+__global__ void wav_norm_coeffs_kernel(const double* __restrict__ part, const int32_t* __restrict__ counts, long L, int B,
+                                       float* __restrict__ coef) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const long n = counts ? counts[b] : L;
+    double s = 0.0, q = 0.0;
+    for (int p = 0; p < kNormParts; ++p) {
+        s += part[((long)b * kNormParts + p) * 2];
+        q += part[((long)b * kNormParts + p) * 2 + 1];
+    }
+    const double mean = n > 0 ? s / (double)n : 0.0;
+    double var = n > 0 ? q / (double)n - mean * mean : 0.0;
+    var = var > 0.0 ? var : 0.0;
+    coef[2 * b] = (float)mean;
+    coef[2 * b + 1] = (float)(1.0 / sqrt(var + 1e-7));
+}
+
+__global__ __launch_bounds__(256) void wav_norm_apply_kernel(const float* __restrict__ x, long L, const int32_t* __restrict__ counts,
+                                                             const float* __restrict__ coef, float pad, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const long n = counts ? counts[b] : L;
+    const float mean = coef[2 * b], rstd = coef[2 * b + 1];
+    const float* xb = x + (long)b * L;
+    float* ob = out + (long)b * L;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long)gridDim.x * 256)
+        ob[i] = i < n ? (xb[i] - mean) * rstd : pad;
+}
+
+size_t normalize_scratch_bytes(int B) { return ((size_t)B * (kNormParts * 2 * sizeof(double) + 2 * sizeof(float) + sizeof(int32_t)) + 255) & ~size_t(255); }
+
+hipError_t launch_normalize_waveform(const float* wav, const int32_t* mask, int B, long L, float pad, float* out, void* scratch,
+                                     hipStream_t s) {
+    if (B <= 0 || B > 65535 || L <= 0) return hipErrorInvalidValue;
+    double* part = reinterpret_cast<double*>(scratch);
+    float* coef = reinterpret_cast<float*>(part + (size_t)B * kNormParts * 2);
+    int32_t* counts = nullptr;
+    if (mask) {
+        counts = reinterpret_cast<int32_t*>(coef + (size_t)2 * B);
+        hipError_t e = hipMemsetAsync(counts, 0, (size_t)B * sizeof(int32_t), s);
+        if (e != hipSuccess) return e;
+        long parts = (L + 65535) / 65536;
+        parts = parts < 1 ? 1 : (parts > 256 ? 256 : parts);
+        hipLaunchKernelGGL(mask_count_kernel, dim3((unsigned)parts, B), dim3(256), 0, s, mask, L, counts);
+    }
+    hipLaunchKernelGGL(wav_moments_kernel, dim3(kNormParts, B), dim3(256), 0, s, wav, L, counts, part);
+    hipLaunchKernelGGL(wav_norm_coeffs_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, counts, L, B, coef);
+    long blocks = (L + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(wav_norm_apply_kernel, dim3((unsigned)blocks, B), dim3(256), 0, s, wav, L, counts, coef, pad, out);
+    return hipGetLastError();
+}
+
 // Token-level valid counts for the text front end: frames[b] = sum_t mask[b,t] (the encoder's key mask is a prefix mask:
 // the tokenizer pads on the right), or T without a mask.
 __global__ void token_counts_kernel(const int32_t* __restrict__ mask, int B, int T, int32_t* __restrict__ frames) {

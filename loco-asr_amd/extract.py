@@ -90,6 +90,42 @@ def load_state_dict_file(path):
     return {k: (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))) for k, v in sd.items()}
 
 
+def extract_text(args, items, classes, encode_labels, device, world, rank):
+    """The reference's text branch (…base…py:79-93): SpeechT5ForTextToSpeech(...).speecht5.encoder(texts.input_ids) -- ids
+    padded to the longest transcript of the batch with <pad> = 1 and NO attention mask -- one pickle per utterance."""
+    if args.random_init:
+        _, enc_sd = la.synth.split_state_dict(la.synth.encoder_state_dict(0))
+        enc_sd = {k: torch.from_numpy(v) for k, v in enc_sd.items()}
+        tpre = {k[len("text_prenet."):]: torch.from_numpy(np.asarray(v)) for k, v in la.synth.text_prenet_state_dict(0).items()}
+    else:
+        tpre, enc_sd = load_state_dict_file(args.text_prenet_state_dict), load_state_dict_file(args.encoder_state_dict)
+    model = la.SpeechT5ForTextToSpeechMI355X.from_state_dicts(tpre, enc_sd).to(device)
+    print("Loaded model")
+    model.eval()
+    if args.synthetic:
+        lens = [8 + (37 * i) % 90 for i in range(len(items))]
+        tokenize = lambda idx: [la.synth.token_ids(1, lens[i], seed=100 + i)[0][0] for i in idx]
+    else:
+        try:
+            from transformers import SpeechT5Tokenizer
+            tok = SpeechT5Tokenizer.from_pretrained(args.tokenizer)
+        except Exception as e:  # no hub access / no local files: say what is needed instead of a stack trace
+            raise SystemExit(f"-m text needs the SpeechT5 tokenizer files (--tokenizer DIR with spm_char.model): {e}")
+        tokenize = lambda idx: [np.asarray(tok(items[i][1])["input_ids"], dtype=np.int64) for i in idx]
+    mine = list(range(rank, len(items), world))
+    with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
+        for k in range(0, len(mine), args.batch_size):
+            idx = mine[k:k + args.batch_size]
+            seqs = tokenize(idx)
+            T = max(len(q) for q in seqs)
+            ids = np.full((len(seqs), T), 1, dtype=np.int64)  # padding="longest" with pad_token_id = 1
+            for r, q in enumerate(seqs):
+                ids[r, :len(q)] = q
+            emb = model.speecht5.encoder(torch.from_numpy(ids).to(device)).last_hidden_state
+            sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+    print("Done!")
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Extract SpeechT5 speech-encoder embeddings on MI355X")
     ap.add_argument("--modality", "-m", choices=["text", "audio"], required=True)
@@ -104,14 +140,19 @@ def main(argv=None):
     ap.add_argument("--synthetic-seconds", type=float, default=5.0)
     ap.add_argument("--classes-file", default=None, help="one intent label per line (the reference's ALL_CLASSES)")
     ap.add_argument("--do-normalize", action="store_true")
+    ap.add_argument("--normalize-on-device", action="store_true",
+                    help="with --do-normalize: run zero_mean_unit_var_norm on the GPU right after the H2D copy instead of in numpy")
+    ap.add_argument("--text-prenet-state-dict", default="extracted/speecht5/mapping/text_prenet_state_dict.pickle")
+    ap.add_argument("--tokenizer", default="microsoft/speecht5_asr",
+                    help="-m text: name or local directory of the SpeechT5 tokenizer (the reference's processor, …base…py:38)")
     ap.add_argument("--format", choices=["pickle", "npy"], default="pickle")
     ap.add_argument("--gather", action="store_true", help="all-gather embeddings so that rank 0 writes everything")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
     args = ap.parse_args(argv)
-    if args.modality == "text":
-        raise SystemExit("-m text: the text prenet path is outside the MI355X hot path (SURVEY.md §2a rows 1-2)")
+    if args.modality == "text" and (args.window_seconds > 0 or args.gather):
+        raise SystemExit("-m text: --window-seconds / --gather apply to audio only")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +205,9 @@ def main(argv=None):
     print(f"{args.split} set size: {len(items)}")
     encode_labels = one_hot_encoder(classes)
 
+    if args.modality == "text":
+        return extract_text(args, items, classes, encode_labels, device, world, rank)
+
     # ---- model
     if args.random_init:
         pre, enc_sd = la.synth.split_state_dict(la.synth.encoder_state_dict(0))
@@ -174,7 +218,8 @@ def main(argv=None):
     model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts(pre, enc_sd).to(device)
     print("Loaded model")
     model.eval()
-    processor = la.SpeechT5FeatureExtractorMI355X(do_normalize=args.do_normalize, pin_memory=True)
+    processor = la.SpeechT5FeatureExtractorMI355X(do_normalize=args.do_normalize, pin_memory=True,
+                                                  normalize_on_device=args.do_normalize and args.normalize_on_device)
 
     shards = [dp.shard_units(lengths, world, r) if any(lengths) else list(range(r, len(items), world)) for r in range(world)]
     mine = shards[rank]

@@ -9,8 +9,10 @@ the longest one, return ``input_values`` f32 [B, L] and ``attention_mask`` i32 [
 UNPADDED samples with epsilon 1e-7 (feature_extraction_speecht5.py:119-138).  The class default is
 ``do_normalize=False`` (:77); the hub checkpoint's value cannot be checked offline, so both are supported.
 
-This stays Python/numpy on the host exactly as in the reference; it hands over pinned host tensors so the
-H2D copy in ``.to(device)`` can overlap compute.
+Padding stays Python/numpy on the host exactly as in the reference; it hands over pinned host tensors so the
+H2D copy in ``.to(device)`` can overlap compute.  With ``normalize_on_device=True`` the zero-mean/unit-variance step is
+deferred to the GPU (``loco_op_normalize_waveform``): ``BatchFeature.to("cuda")`` runs it in place
+right after the copy, so ``processor(...).to(device)`` keeps the reference's shape and the host does no arithmetic.
 """
 from __future__ import annotations
 
@@ -18,8 +20,35 @@ import numpy as np
 import torch
 
 
+def normalize_waveform_(input_values: torch.Tensor, attention_mask=None, padding_value: float = 0.0) -> torch.Tensor:
+    """In-place ``zero_mean_unit_var_norm`` of a [B, L] fp32 batch ON THE GPU (HF feature_extraction_speecht5.py:119-138)."""
+    import ctypes as C
+
+    from . import _lib
+    if input_values.device.type != "cuda":
+        raise RuntimeError("normalize_waveform_ runs on the GPU only (the host path is SpeechT5FeatureExtractorMI355X(do_normalize=True))")
+    if input_values.dim() != 2 or input_values.dtype != torch.float32 or not input_values.is_contiguous():
+        raise ValueError("input_values must be a contiguous fp32 [batch, samples] tensor")
+    lib = _lib.load()
+    B, L = input_values.shape
+    m = None
+    if attention_mask is not None:
+        if attention_mask.shape != input_values.shape:
+            raise ValueError("attention_mask does not match input_values")
+        m = attention_mask.to(device=input_values.device, dtype=torch.int32).contiguous()
+    with torch.cuda.device(input_values.device):
+        scratch = torch.empty(int(lib.loco_normalize_scratch_bytes(B)), dtype=torch.uint8, device=input_values.device)
+        stream = C.c_void_p(torch.cuda.current_stream(input_values.device).cuda_stream)
+        _lib.check(lib.loco_op_normalize_waveform(C.c_void_p(input_values.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
+                                                  B, L, float(padding_value), C.c_void_p(input_values.data_ptr()),
+                                                  C.c_void_p(scratch.data_ptr()), scratch.numel(), stream), "normalize_waveform")
+    return input_values
+
+
 class BatchFeature(dict):
     """dict with ``.to(device)`` and attribute access, so ``encoder(**audios)`` works as in the reference."""
+
+    _pending_normalize = None  # padding_value when the normalisation was deferred to the device
 
     def __getattr__(self, k):
         try:
@@ -28,17 +57,24 @@ class BatchFeature(dict):
             raise AttributeError(k) from e
 
     def to(self, device, non_blocking: bool = True):
-        return BatchFeature({k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in self.items()})
+        out = BatchFeature({k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in self.items()})
+        if self._pending_normalize is not None:
+            if torch.device(device).type == "cuda":
+                normalize_waveform_(out["input_values"], out.get("attention_mask"), self._pending_normalize)
+            else:
+                out._pending_normalize = self._pending_normalize  # still owed; only a GPU can pay it
+        return out
 
 
 class SpeechT5FeatureExtractorMI355X:
     model_input_names = ["input_values", "attention_mask"]
 
     def __init__(self, sampling_rate: int = 16000, padding_value: float = 0.0, do_normalize: bool = False,
-                 return_attention_mask: bool = True, pin_memory: bool = False):
+                 return_attention_mask: bool = True, pin_memory: bool = False, normalize_on_device: bool = False):
         self.sampling_rate = sampling_rate
         self.padding_value = padding_value
         self.do_normalize = do_normalize
+        self.normalize_on_device = normalize_on_device  # defer do_normalize to BatchFeature.to("cuda")
         self.return_attention_mask = return_attention_mask
         self.pin_memory = pin_memory
 
@@ -56,7 +92,10 @@ class SpeechT5FeatureExtractorMI355X:
         clips = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audio]
         if not clips:
             raise ValueError("empty batch")
-        if self.do_normalize:
+        defer = self.do_normalize and self.normalize_on_device
+        if defer and (return_tensors == "np" or not self.return_attention_mask):
+            raise ValueError("normalize_on_device needs torch tensors and the attention mask (the device op reads the clip lengths from it)")
+        if self.do_normalize and not defer:
             clips = [self.zero_mean_unit_var_norm(c) for c in clips]
         lmax = max(len(c) for c in clips) if padding in ("longest", True) else None
         if lmax is None:
@@ -76,4 +115,6 @@ class SpeechT5FeatureExtractorMI355X:
             out["attention_mask"] = m
         if return_tensors == "np":
             out = BatchFeature({k: v.numpy() for k, v in out.items()})
+        if defer:
+            out._pending_normalize = float(self.padding_value)
         return out

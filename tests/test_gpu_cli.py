@@ -41,10 +41,50 @@ def test_extract_cli_synthetic(tmp_path, oracle):
             assert d["target"].shape == (101,) and d["target"].sum() == 1 and d["target"][i % 101] == 1
 
 
-def test_text_modality_is_refused():
+def test_extract_cli_text_modality(tmp_path, oracle):
+    """-m text (…base…py:79-93): synthetic token ids -> text prenet + encoder -> the same per-utterance pickles; ids are
+    padded with <pad> = 1 and NO mask is passed, exactly like `model.speecht5.encoder(texts.input_ids)`."""
+    la = importlib.import_module("loco-asr_amd")
     extract = importlib.import_module("loco-asr_amd.extract")
-    with pytest.raises(SystemExit):
-        extract.main(["-m", "text", "-s", "devel"])
+    out = str(tmp_path / "extracted" / "speecht5_base")
+    extract.main(["-m", "text", "-s", "devel", "--synthetic", "5", "--random-init", "--batch-size", "3", "--out", out])
+    sd = la.synth.encoder_state_dict(0)
+    sd.update(la.synth.text_prenet_state_dict(0))
+    lens = [8 + (37 * i) % 90 for i in range(5)]
+    for idx in ([0, 1, 2], [3, 4]):
+        seqs = [la.synth.token_ids(1, lens[i], seed=100 + i)[0][0] for i in idx]
+        T = max(len(q) for q in seqs)
+        ids = np.full((len(seqs), T), 1, dtype=np.int64)
+        for r, q in enumerate(seqs):
+            ids[r, :len(q)] = q
+        ref = oracle.encode_text(ids, None, sd)
+        for row, i in enumerate(idx):
+            with open(os.path.join(out, "devel", "text", f"synthetic-{i:06d}_embedding_and_target.pickle"), "rb") as fh:
+                d = pickle.load(fh)
+            assert d["embedding"].shape == (T, 768) and d["embedding"].dtype == np.float32
+            assert np.linalg.norm(d["embedding"] - ref[row].numpy()) / np.linalg.norm(ref[row].numpy()) < 1e-4
+    # a real corpus needs the tokenizer files, which are not in the container: a clear message, not a stack trace
+    import json
+    os.makedirs(tmp_path / "slurp" / "dataset" / "slurp")
+    with open(tmp_path / "slurp" / "dataset" / "slurp" / "devel.jsonl", "w") as fh:
+        fh.write(json.dumps({"slurp_id": 7, "sentence": "wake me up at nine", "intent": "alarm_set", "recordings": [{"file": "a.flac"}]}) + "\n")
+    with pytest.raises(SystemExit, match="tokenizer"):
+        extract.main(["-m", "text", "-s", "devel", "--data-path", str(tmp_path / "slurp"), "--random-init", "--out", out,
+                      "--tokenizer", str(tmp_path / "no_tokenizer_here")])
+
+
+def test_extract_cli_normalize_on_device_equals_host(tmp_path):
+    extract = importlib.import_module("loco-asr_amd.extract")
+    a, b = str(tmp_path / "host"), str(tmp_path / "dev")
+    common = ["-m", "audio", "-s", "devel", "--synthetic", "3", "--synthetic-seconds", "1", "--random-init", "--batch-size", "3",
+              "--do-normalize"]
+    extract.main(common + ["--out", a])
+    extract.main(common + ["--normalize-on-device", "--out", b])
+    for i in range(3):
+        name = os.path.join("devel", "audio", f"synthetic-{i:06d}_embedding_and_target.pickle")
+        ea = pickle.load(open(os.path.join(a, name), "rb"))["embedding"]
+        eb = pickle.load(open(os.path.join(b, name), "rb"))["embedding"]
+        assert np.linalg.norm(ea - eb) / np.linalg.norm(ea) < 2e-5
 
 
 def test_extract_then_train_head_pipeline(tmp_path):

@@ -349,3 +349,47 @@ def test_gemm_f16x3_batched_strided_conv_large():
     out = (chi.float() + clo.float()).view(B, Tout, Cc).cpu()
     assert rel_l2(out[:, idx], ref[:, idx]) < 5e-6
     assert rel_l2(out, ref) < 5e-6
+
+
+def test_normalize_waveform_on_device_matches_hf_golden():
+    """"next" row f-4: SpeechT5FeatureExtractor(do_normalize=True) on the device against HF's own output (fixture g7):
+    values, padding, reproducibility, the mask-free form, and the feature extractor's deferred path end to end."""
+    from conftest import golden
+    g = golden("g7_normalize.npz")
+    lengths = [int(n) for n in g["lengths"]]
+    clips = [(la.synth.clip(i, n) * np.float32(0.5 + i) + np.float32(0.1 * i - 0.15)).astype(np.float32) for i, n in enumerate(lengths)]
+    fe = la.SpeechT5FeatureExtractorMI355X(do_normalize=True, normalize_on_device=True)
+    feats = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest").to("cuda")
+    x = feats["input_values"]
+    assert feats._pending_normalize is None
+    cols = torch.from_numpy(g["cols"]).cuda()
+    assert float((x[:, cols].cpu() - torch.from_numpy(g["values"])).abs().max()) < 3e-6
+    assert float((x[0].cpu() - torch.from_numpy(g["first_clip"])).abs().max()) < 3e-6
+    for i, n in enumerate(lengths):
+        var = float(clips[i].astype(np.float64).var())  # unit variance up to the 1e-7 epsilon under the root
+        assert abs(float(x[i, :n].double().mean())) < 1e-6
+        assert abs(float(x[i, :n].double().std(unbiased=False)) - (var / (var + 1e-7)) ** 0.5) < 2e-6
+        assert n == 16000 or float(x[i, n:].abs().max()) == 0.0
+    # bitwise reproducible, and out-of-place == in-place
+    raw = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+    xin, msk = raw["input_values"].cuda(), raw["attention_mask"].cuda()
+    out = torch.empty_like(xin)
+    scratch = torch.empty(int(lib().loco_normalize_scratch_bytes(4)), dtype=torch.uint8, device="cuda")
+    check(lib().loco_op_normalize_waveform(ptr(xin), ptr(msk), 4, 16000, 0.0, ptr(out), ptr(scratch), scratch.numel(), stream()))
+    assert torch.equal(out, x)
+    # no mask: every sample counts; padding_value is honoured
+    one = torch.from_numpy(clips[2]).cuda()[None].contiguous()
+    o2 = torch.empty_like(one)
+    check(lib().loco_op_normalize_waveform(ptr(one), None, 1, one.shape[1], -7.0, ptr(o2), ptr(scratch), scratch.numel(), stream()))
+    ref = (clips[2].astype(np.float64) - clips[2].astype(np.float64).mean()) / np.sqrt(clips[2].astype(np.float64).var() + 1e-7)
+    assert float((o2[0].double().cpu() - torch.from_numpy(ref)).abs().max()) < 2e-6
+    m1 = torch.ones(1, one.shape[1], dtype=torch.int32, device="cuda")
+    m1[0, 5000:] = 0
+    check(lib().loco_op_normalize_waveform(ptr(one), ptr(m1), 1, one.shape[1], -7.0, ptr(o2), ptr(scratch), scratch.numel(), stream()))
+    assert float(o2[0, 5000:].min()) == -7.0 and float(o2[0, 5000:].max()) == -7.0
+    # end to end: the encoder on the device-normalised batch reproduces HF on HF's normalised batch
+    from gpu_util import model
+    m, _ = model()
+    y = m.speecht5.encoder(**feats).last_hidden_state
+    assert rel_l2(y[:, [0, 1, 20, 37, 48]], g["last_hidden_state"]) < 2e-5
+    assert abs(float(y.double().norm()) / g["out_stats"][0] - 1) < 2e-5

@@ -159,3 +159,32 @@ def test_window_units_for_long_recordings():
     assert [x for x in u if x[0] == 3] == [(3, 0, ten), (3, ten, 2 * ten), (3, 2 * ten, 2 * ten + 400)]
     shards = [dp.shard_units([b - a for _, a, b in u], 8, r) for r in range(8)]
     assert sorted(i for s in shards for i in s) == list(range(len(u)))
+
+
+def _g7_clips():
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g7_normalize.npz"))
+    clips = [(la.synth.clip(i, int(n)) * np.float32(0.5 + i) + np.float32(0.1 * i - 0.15)).astype(np.float32) for i, n in enumerate(g["lengths"])]
+    return g, clips
+
+
+def test_feature_extractor_do_normalize_matches_hf_golden():
+    """do_normalize=True on the host against HF's SpeechT5FeatureExtractor output (fixture g7)."""
+    g, clips = _g7_clips()
+    fe = la.SpeechT5FeatureExtractorMI355X(do_normalize=True)
+    out = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+    x = out["input_values"].numpy()
+    assert x.shape == (4, 16000) and out["attention_mask"].sum(1).tolist() == g["mask_sums"].tolist()
+    np.testing.assert_allclose(x[:, g["cols"]], g["values"], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(x[0], g["first_clip"], rtol=2e-6, atol=2e-6)
+
+
+def test_feature_extractor_defers_normalisation_to_the_device():
+    """normalize_on_device: the host only pads; the debt travels with the BatchFeature until a GPU pays it."""
+    g, clips = _g7_clips()
+    fe = la.SpeechT5FeatureExtractorMI355X(do_normalize=True, normalize_on_device=True)
+    out = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+    assert out._pending_normalize == 0.0
+    np.testing.assert_array_equal(out["input_values"][1, :12345].numpy(), clips[1])  # untouched on the host
+    assert out.to("cpu")._pending_normalize == 0.0
+    with pytest.raises(ValueError):
+        fe(audio=clips, sampling_rate=16000, return_tensors="np")
