@@ -217,6 +217,15 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
                        int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2, int64_t sA1, int64_t sA2,
                        int64_t sC1, int64_t sC2, void* stream);
 
+/* The same GEMM with the split-K workspace loco_forward hands it for small problems (M <= 512 and a grid that cannot
+ * fill the chip): K is cut into slices computed side by side, partial sums (fp32, >= loco_gemm_splitk_bytes()) are added in
+ * a fixed order by a second kernel that applies the epilogue.  Larger problems ignore the workspace. */
+size_t loco_gemm_splitk_bytes(void);
+int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
+                              const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc,
+                              int32_t M, int32_t N, int32_t K, int32_t epilogue, void* splitk_ws, size_t splitk_bytes,
+                              void* stream);
+
 /* split-precision attention core: q, k as fp16 hi/lo planes [B*T,768] (q pre-scaled by 1/8), v TRANSPOSED per head as
  * planes [(b*12+head)*64+d][Tp] with Tp % 64 == 0 and zero padding for t >= T, frame t stored in column
  * loco_op_vt_column(t) (a permutation inside each aligned group of 16 frames: the order the matrix instruction consumes

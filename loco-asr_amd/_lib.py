@@ -65,6 +65,9 @@ SIGNATURES = {
     "loco_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_op_split_f16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "loco_op_vt_column": (C.c_int32, [_i32]),
+    "loco_gemm_splitk_bytes": (_sz, []),
+    "loco_op_gemm_f16x3_splitk": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
+                                            _vp, _sz, _vp]),
     "loco_op_gemm_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                      _i32, _i32, _i64, _i64, _i64, _i64, _vp]),
     "loco_op_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

@@ -11,11 +11,9 @@
 //
 // Operands arrive ALREADY split -- weights once at load time, activations by the epilogue of the kernel that
 // produced them (same bytes as fp32: 2+2) -- so this kernel moves exactly the bytes of the fp32 GEMM and spends
-// no VALU on conversion.  Structure = gemm_f32.hip: 128x128x32 tile, 4 waves x (2x2) 32x32 sub-tiles,
-// D = W_tile * A_tile^T orientation for 16-byte epilogue accesses, global loads two k-tiles ahead, fragments
-// half a tile ahead, second half after the barrier.  LDS: four fp16 planes (A_hi, A_lo, W_hi, W_lo) of 128 rows x
-// 80 bytes (64 data + 16 pad: a 16-lane ds_read_b128 group covers all 16 sixteen-byte slots), two buffers = 80 KB,
-// two workgroups per CU.
+// no VALU on conversion.  One kernel template (gemm_f16x3_dma_kernel, below) covers every shape: 256x256, 256x128 and
+// 128x128 tiles on an LDS ring filled by LDS-DMA, 64x64 per wave, D = W_tile * A_tile^T orientation; small problems add
+// split-K with a fixed-order reduction (launch_gemm_split).
 #include "loco_kernels.h"
 
 namespace loco {
@@ -138,172 +136,9 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
 }
 
 constexpr int SBK = 32;
-constexpr int SLD = SBK + 8;  // halves per LDS row (80 bytes)
-
-// WM x WN waves, each 64x64: block tile (64 WM) x (64 WN).  2x2 (128x128, 80 KB LDS, two workgroups per CU) or
-// 4x2 (256x128, 120 KB, one 8-wave workgroup per CU: 25 % fewer L2 bytes per FLOP -- this kernel runs 3x faster
-// than the fp32 one on the same bytes, so operand traffic, not the matrix pipe, is what it leans on).
-template <int EPI, bool OUT_SPLIT, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_f16x3_kernel(GemmSplitArgs p, int tiles_m, int tiles_n, int nblk) {
-    constexpr int SBM = 64 * WM, SBN = 64 * WN, NT = 64 * WM * WN;
-    constexpr int APLANE = SBM * SLD, WPLANE = SBN * SLD;  // halves per plane
-    constexpr int SBUF = 2 * APLANE + 2 * WPLANE;          // A_hi, A_lo, W_hi, W_lo
-    constexpr int RPP = NT / 4;                            // rows staged per pass
-    constexpr int NA = SBM / RPP, NW = SBN / RPP;          // 16-byte pieces per thread per plane
-    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * SBUF];
-
-    // XCD-aware bijective tile map (see gemm_f32.hip)
-    int mt, nt, z;
-    {
-        const int q = nblk >> 3, rr = nblk & 7;
-        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int t = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
-        nt = t % tiles_n;
-        const int rest = t / tiles_n;
-        mt = rest % tiles_m;
-        z = rest / tiles_m;
-    }
-    const int z1 = z / p.nb2, z2 = z % p.nb2;
-    const long aoff = z1 * p.sA1 + z2 * p.sA2;
-    const long coff = z1 * p.sC1 + z2 * p.sC2;
-    const int m0 = mt * SBM, n0 = nt * SBN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, h = lane >> 5;
-
-    // staging: 16-byte piece f = tid + NT*q of a (rows x 64-byte) plane tile -> row f/4, piece f%4
-    const int srow = tid >> 2, sk = (tid & 3) * 8;
-    long ga[NA], gw[NW];
-#pragma unroll
-    for (int q = 0; q < NA; ++q) {
-        int ra = m0 + srow + RPP * q;
-        ra = ra < p.M ? ra : p.M - 1;
-        ga[q] = aoff + (long)ra * p.lda + sk;
-    }
-#pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        int rw = n0 + srow + RPP * q;
-        rw = rw < p.N ? rw : p.N - 1;
-        gw[q] = (long)rw * p.ldw + sk;
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    h8 s0[2 * NA + 2 * NW], s1[2 * NA + 2 * NW];  // staging sets: [Ahi | Alo | Whi | Wlo]
-#define SP_GLOAD(S, kt)                                                                      \
-    _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                         \
-        S[q] = *reinterpret_cast<const h8*>(p.Ahi + ga[q] + (long)(kt) * SBK);               \
-        S[NA + q] = *reinterpret_cast<const h8*>(p.Alo + ga[q] + (long)(kt) * SBK);          \
-    }                                                                                        \
-    _Pragma("unroll") for (int q = 0; q < NW; ++q) {                                         \
-        S[2 * NA + q] = *reinterpret_cast<const h8*>(p.Whi + gw[q] + (long)(kt) * SBK);      \
-        S[2 * NA + NW + q] = *reinterpret_cast<const h8*>(p.Wlo + gw[q] + (long)(kt) * SBK); \
-    }
-#define SP_LSTORE(S, buf)                                                                                          \
-    _Pragma("unroll") for (int q = 0; q < NA; ++q) {                                                               \
-        *reinterpret_cast<h8*>(lds + (buf) * SBUF + (srow + RPP * q) * SLD + sk) = S[q];                           \
-        *reinterpret_cast<h8*>(lds + (buf) * SBUF + APLANE + (srow + RPP * q) * SLD + sk) = S[NA + q];             \
-    }                                                                                                              \
-    _Pragma("unroll") for (int q = 0; q < NW; ++q) {                                                               \
-        *reinterpret_cast<h8*>(lds + (buf) * SBUF + 2 * APLANE + (srow + RPP * q) * SLD + sk) = S[2 * NA + q];     \
-        *reinterpret_cast<h8*>(lds + (buf) * SBUF + 2 * APLANE + WPLANE + (srow + RPP * q) * SLD + sk) = S[2 * NA + NW + q]; \
-    }
-
-    SP_GLOAD(s0, 0)
-    SP_LSTORE(s0, 0)
-    const int nk = p.K / SBK;
-    if (nk > 1) { SP_GLOAD(s0, 1) }
-    __syncthreads();
-
-    const int fa = (wm * 64 + r) * SLD + 8 * h;
-    const int fw = (wn * 64 + r) * SLD + 8 * h;
-    // fragments of k-step ks: F[0..1] = A_hi rows {0,32}, F[2..3] = A_lo, F[4..5] = W_hi, F[6..7] = W_lo
-#define SP_FRAGS(buf, ks, F)                                                                                     \
-    {                                                                                                            \
-        const _Float16* b_ = lds + (buf) * SBUF + 16 * (ks);                                                     \
-        F[0] = *reinterpret_cast<const h8*>(b_ + fa);                                                            \
-        F[1] = *reinterpret_cast<const h8*>(b_ + fa + 32 * SLD);                                                 \
-        F[2] = *reinterpret_cast<const h8*>(b_ + APLANE + fa);                                                   \
-        F[3] = *reinterpret_cast<const h8*>(b_ + APLANE + fa + 32 * SLD);                                        \
-        F[4] = *reinterpret_cast<const h8*>(b_ + 2 * APLANE + fw);                                               \
-        F[5] = *reinterpret_cast<const h8*>(b_ + 2 * APLANE + fw + 32 * SLD);                                    \
-        F[6] = *reinterpret_cast<const h8*>(b_ + 2 * APLANE + WPLANE + fw);                                      \
-        F[7] = *reinterpret_cast<const h8*>(b_ + 2 * APLANE + WPLANE + fw + 32 * SLD);                           \
-    }
-    // 12 MFMAs: small terms first, then hi*hi
-#define SP_MFMA(F)                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[6 + j], F[i], acc[i][j], 0, 0, 0);              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[2 + i], acc[i][j], 0, 0, 0);          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[i], acc[i][j], 0, 0, 0);              \
-        }
-
-    int cur = 0;
-    h8 fx[8], fy[8];
-    SP_FRAGS(0, 0, fx)
-#define SP_KTILE(SCUR, SNEXT)                                         \
-    {                                                                 \
-        const bool more = kt + 1 < nk;                                \
-        if (kt + 2 < nk) { SP_GLOAD(SNEXT, kt + 2) }                  \
-        SP_FRAGS(cur, 1, fy)                                          \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        SP_MFMA(fx)                                                   \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        if (more) { SP_LSTORE(SCUR, cur ^ 1) }                        \
-        __syncthreads();                                              \
-        cur ^= 1;                                                     \
-        if (more) { SP_FRAGS(cur, 0, fx) }                            \
-        __builtin_amdgcn_sched_barrier(0);                            \
-        SP_MFMA(fy)                                                   \
-        __builtin_amdgcn_sched_barrier(0);                            \
-    }
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        SP_KTILE(s0, s1)
-        ++kt;
-        SP_KTILE(s1, s0)
-        --kt;
-    }
-    if (kt < nk) SP_KTILE(s0, s1)
-#undef SP_KTILE
-#undef SP_MFMA
-#undef SP_FRAGS
-#undef SP_LSTORE
-#undef SP_GLOAD
-
-    // epilogue: acc[i][j][e] = C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-                if (n < p.N) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
-                }
-            }
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant: 256x128x32 tile, 8 waves (4 x 2), ONE workgroup per CU, three-stage LDS ring filled by
+// The GEMM kernel: 256x128x32 tile, 8 waves (4 x 2), ONE workgroup per CU, three-stage LDS ring filled by
 // global_load_lds_dwordx4 (no staging VGPRs, no ds_write): tile kt+2 is in flight while tile kt is consumed, retired
 // with a counted s_waitcnt vmcnt (never 0 inside the loop) and a raw s_barrier.  The DMA writes 1 KiB contiguously
 // per wave-instruction (16 rows x 64 B of one plane), so rows cannot be padded; bank conflicts are removed by an XOR
@@ -313,7 +148,7 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // WM x WN waves of 64x64: 4x2 = 256x128 tile, 3-stage ring (144 KiB); 4x4 = 256x256 tile, 16 waves, 2 stages (128 KiB):
-// half the L2->LDS bytes per FLOP of the 128x128 tile.
+// half the L2->LDS bytes per FLOP of the 128x128 tile; 2x2 = 128x128 tile, 3 stages (96 KiB) for small M.
 // MF16: issue v_mfma_f32_16x16x32_f16 (16 accumulators of 16x16 per wave) instead of 32x32x16 (4 of 32x32): same FLOPs,
 // LDS bytes and registers, but the chip sustains a higher clock on that shape when the matrix pipes are the power draw.
 // NJ: 16-column sub-tiles each wave actually computes (4, or 3 when N = 48: the positional conv's 48 outputs per group).
@@ -555,6 +390,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_ke
     }
 }
 
+// Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns.
+template <int EPI, bool OUT_SPLIT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int ks) {
+    const long n4 = (long)p.M * (p.N / 4);
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int m = (int)(i / (p.N / 4));
+    const int n = 4 * (int)(i - (long)m * (p.N / 4));
+    const float* part = p.splitk_ws + (long)m * p.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part);
+    for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (long)k * p.M * p.N);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    split_gemm_store<EPI, OUT_SPLIT>(p, v, 0, m, n);
+}
+
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % SBK != 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.sA1 | a.sA2) & 7) return hipErrorInvalidValue;  // 16-byte staging of 8 halves
@@ -574,6 +424,44 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
                            (int)nb);
         return hipGetLastError();
+    }
+    // Split-K for grids that cannot fill the chip (one 5 s utterance: M = 249 -> 12 workgroups for the FFN's second GEMM,
+    // each walking K = 3072 in 96 dependent steps that are bound by HBM latency, not bandwidth): the K range is cut into ks
+    // slices computed as a batch dimension of the same kernel (fp32 partial sums in a workspace), then summed in a fixed
+    // order -- bitwise reproducible -- by a reduction kernel that applies the epilogue.
+    if (a.splitk_ws && a.nb1 * a.nb2 == 1 && a.M <= kSplitKMaxM) {
+        const int bm = a.M >= 1024 ? 256 : 128;  // the tile the dispatch below picks for this M (N tile 128)
+        const int tm = (a.M + bm - 1) / bm, tn = (a.N + 127) / 128;
+        int ks = 256 / (tm * tn);
+        if (ks > a.K / 256) ks = a.K / 256;  // >= 8 k-steps per slice
+        while (ks > 1 && a.K % (ks * SBK) != 0) --ks;
+        if (ks >= 2) {
+            GemmSplitArgs b = a;
+            const int kslice = a.K / ks;
+            b.splitk_ws = nullptr;
+            b.bias = nullptr; b.R = nullptr; b.Chi = nullptr; b.Clo = nullptr;
+            b.C = a.splitk_ws; b.ldc = a.N;
+            b.nb1 = 1; b.nb2 = ks; b.sA1 = 0; b.sC1 = 0;
+            b.sA2 = kslice; b.sW2 = kslice; b.sC2 = (long)a.M * a.N; b.sBias2 = 0;
+            b.K = kslice;
+            b.epilogue = kEpiNone;
+            hipError_t err = launch_gemm_split(b, s);
+            if (err != hipSuccess) return err;
+            const long n4 = (long)a.M * (a.N / 4);
+            const unsigned blocks = (unsigned)((n4 + 255) / 256);
+#define RED_LAUNCH(EPI)                                                                                                  \
+            if (split || EPI == kEpiQkvScatter) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, true>), dim3(blocks), dim3(256), 0, s, a, ks); \
+            else hipLaunchKernelGGL((splitk_reduce_kernel<EPI, false>), dim3(blocks), dim3(256), 0, s, a, ks);
+            switch (a.epilogue) {
+                case kEpiNone: RED_LAUNCH(kEpiNone) break;
+                case kEpiGelu: RED_LAUNCH(kEpiGelu) break;
+                case kEpiResidual: RED_LAUNCH(kEpiResidual) break;
+                case kEpiQkvScatter: RED_LAUNCH(kEpiQkvScatter) break;
+                default: return hipErrorInvalidValue;
+            }
+#undef RED_LAUNCH
+            return hipGetLastError();
+        }
     }
     // Variant choice (tools/gemm_split_bench.py, MI355X): the LDS-DMA ring kernels win whenever there are enough rows to
     // fill 256-row tiles; the 256x256 / 16-wave form is ~5 % ahead when it still yields >= 3 full rounds of 256
@@ -610,28 +498,21 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
 #undef DMA_LAUNCH2
         return hipGetLastError();
     }
-    const bool big = false;
-    const int bm = big ? 256 : 128, bn = 128;
-    const int tiles_m = (a.M + bm - 1) / bm, tiles_n = (a.N + bn - 1) / bn;
-    const long nblk = (long)tiles_m * tiles_n * a.nb1 * a.nb2;
-    if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
-    dim3 grid((unsigned)nblk), block(big ? 512 : 256);
-#define SP_LAUNCH(EPI)                                                                                                           \
-    if (big) {                                                                                                                   \
-        if (split) hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, true, 4, 2>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);  \
-        else hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, false, 4, 2>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);       \
-    } else {                                                                                                                     \
-        if (split) hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, true, 2, 2>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);  \
-        else hipLaunchKernelGGL((gemm_f16x3_kernel<EPI, false, 2, 2>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);       \
-    }
+    // small M (short clips, the text branch, tests): the same LDS-DMA ring kernel at 128 x 128 (4 waves, 3 stages)
+    const int tm = (a.M + 127) / 128, tn = (a.N + 127) / 128;
+    const long nb = (long)tm * tn * a.nb1 * a.nb2;
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+#define SM_LAUNCH(EPI)                                                                                                          \
+    if (split) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, 2, 2, 3, true, 4>), dim3((unsigned)nb), dim3(256), 0, s, a, tm, tn, (int)nb); \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, 2, 2, 3, true, 4>), dim3((unsigned)nb), dim3(256), 0, s, a, tm, tn, (int)nb);
     switch (a.epilogue) {
-        case kEpiNone: SP_LAUNCH(kEpiNone) break;
-        case kEpiGelu: SP_LAUNCH(kEpiGelu) break;
-        case kEpiResidual: SP_LAUNCH(kEpiResidual) break;
-        case kEpiQkvScatter: SP_LAUNCH(kEpiQkvScatter) break;
+        case kEpiNone: SM_LAUNCH(kEpiNone) break;
+        case kEpiGelu: SM_LAUNCH(kEpiGelu) break;
+        case kEpiResidual: SM_LAUNCH(kEpiResidual) break;
+        case kEpiQkvScatter: SM_LAUNCH(kEpiQkvScatter) break;
         default: return hipErrorInvalidValue;
     }
-#undef SP_LAUNCH
+#undef SM_LAUNCH
     return hipGetLastError();
 }
 

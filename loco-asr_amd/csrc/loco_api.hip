@@ -105,6 +105,7 @@ struct loco_encoder {
     float* text_pe = nullptr;     // [text_pe_rows, 768]
     int text_pe_rows = 0;
     bool speech_ready = false;    // set by loco_finalize_weights when the speech prenet weights were supplied
+    float* cur_splitk = nullptr;  // split-K workspace of the forward being enqueued (null for large problems)
     // concurrency: a batch may run as two half-batches on two streams (loco_set_streams)
     int streams = 2;
     hipStream_t side = nullptr;
@@ -177,7 +178,9 @@ struct Plan {
     long L;
     long Tc[7];  // conv output lengths
     long T, M;
-    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1, total;
+    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1,
+        off_splitk, total;
+    bool splitk;
 };
 
 void carve_plan(const loco_encoder* e, Plan& p);
@@ -235,6 +238,8 @@ void carve_plan(const loco_encoder* e, Plan& p) {
     p.off_ffn = take((ffn_elems > posg_elems ? ffn_elems : posg_elems) * f);
     p.off_xs0 = take((size_t)p.M * kHidden * f);  // fp16 hi|lo planes of x0 / x1 (precision f16x3)
     p.off_xs1 = take((size_t)p.M * kHidden * f);
+    p.splitk = p.M <= kSplitKMaxM;  // small problems: fp32 partial sums of the split-K GEMM path (gemm_f16x3.hip)
+    p.off_splitk = take(p.splitk ? kSplitKBytes : 0);
     p.total = o;
 }
 
@@ -290,6 +295,7 @@ int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _F
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
         a.T = scatter->T; a.Tp = scatter->Tp;
     }
+    a.splitk_ws = e->cur_splitk;
     const double nb = (double)nb1 * nb2;
     const double flops = 2.0 * M * (double)N * K * nb;
     const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
@@ -910,6 +916,7 @@ int forward_one(loco_encoder* e, const Plan& p, const float* wav, const int32_t*
 
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
     return e->precision == 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
 }
 }  // namespace
@@ -994,6 +1001,7 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
                      reinterpret_cast<float*>(ws + p.off_ctx), reinterpret_cast<float*>(ws + p.off_qkv),
                      reinterpret_cast<float*>(ws + p.off_qp), reinterpret_cast<float*>(ws + p.off_ffn),
                      reinterpret_cast<_Float16*>(ws + p.off_xs0), reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
     return e->precision == 1 ? forward_f16x3(e, p, nullptr, out, hidden_states, bufs, s, true)
                              : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
 }
@@ -1113,6 +1121,21 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
     if (K % 32 || (lda | ldw) & 7) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3: K %% 32 and lda/ldw %% 8 must be 0");
     GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, bias, R, C,
                     (_Float16*)Chi, (_Float16*)Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epilogue};
+    HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+size_t loco_gemm_splitk_bytes(void) { return kSplitKBytes; }
+
+int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
+                              const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc, int32_t M,
+                              int32_t N, int32_t K, int32_t epilogue, void* splitk_ws, size_t splitk_bytes, void* stream) {
+    if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Chi) || !splitk_ws) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3_splitk: null argument");
+    if (K % 32 || (lda | ldw) & 7) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3_splitk: K %% 32 and lda/ldw %% 8 must be 0");
+    if (splitk_bytes < kSplitKBytes) return fail(LOCO_E_WORKSPACE, "loco_op_gemm_f16x3_splitk: workspace %zu < %zu bytes", splitk_bytes, kSplitKBytes);
+    GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, bias, R, C,
+                    (_Float16*)Chi, (_Float16*)Clo, M, N, K, lda, ldw, ldc, ldr, 1, 1, 0, 0, 0, 0, epilogue};
+    a.splitk_ws = reinterpret_cast<float*>(splitk_ws);
     HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
     return LOCO_OK;
 }

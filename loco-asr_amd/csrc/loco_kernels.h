@@ -21,6 +21,10 @@ constexpr int kRelMax = 160;
 constexpr int kRelN = 320;
 constexpr int kQkv = 3 * kHidden;
 
+// Workspace of the split-K path: ks * tiles_m * tiles_n <= 256 tiles of at most 256 x 128 partial sums.
+constexpr size_t kSplitKBytes = (size_t)256 * 256 * 128 * sizeof(float);
+constexpr int kSplitKMaxM = 8192;
+
 enum Epilogue { kEpiNone = 0, kEpiGelu = 1, kEpiResidual = 2, kEpiQkvScatter = 3, kEpiPosConv = 4 };
 
 struct GemmArgs {
@@ -55,6 +59,8 @@ struct GemmSplitArgs {
     // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
     // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp],
     // frame t in column vt_col(t)
+    // split-K for small problems (launch_gemm_split decides): fp32 partial sums [ks][M][N], >= kSplitKBytes when set
+    float* splitk_ws = nullptr;
     _Float16* Khi = nullptr;
     _Float16* Klo = nullptr;
     _Float16* Vthi = nullptr;

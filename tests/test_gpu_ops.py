@@ -393,3 +393,37 @@ def test_normalize_waveform_on_device_matches_hf_golden():
     y = m.speecht5.encoder(**feats).last_hidden_state
     assert rel_l2(y[:, [0, 1, 20, 37, 48]], g["last_hidden_state"]) < 2e-5
     assert abs(float(y.double().norm()) / g["out_stats"][0] - 1) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(249, 768, 3072), (80, 2304, 768), (1, 768, 768), (512, 3072, 768), (300, 320, 64), (1992, 768, 3072),
+                                   (1100, 2304, 768), (8200, 768, 768)])
+@pytest.mark.parametrize("epi,out_split", [(0, False), (1, True), (2, False)])
+def test_gemm_f16x3_split_k(M, N, K, epi, out_split):
+    """Small problems cut K into slices (partials + fixed-order reduction with the epilogue): same accuracy bar as the
+    single-pass kernel, bitwise reproducible; grids that already fill the chip, K too short and M > 8192 take the single pass."""
+    A = hu("sk.a", (M, K), 2.0)
+    W = hu("sk.w", (N, K), 2.0 / math.sqrt(K))
+    b = hu("sk.b", (N,))
+    R = hu("sk.r", (M, N))
+    ahi, alo = split16(A)
+    whi, wlo = split16(W)
+    bd, Rd = dev(b), dev(R)
+    ws = torch.empty(int(lib().loco_gemm_splitk_bytes()), dtype=torch.uint8, device="cuda")
+
+    def run():
+        C_ = torch.empty(M, N, device="cuda")
+        chi = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        clo = torch.empty_like(chi)
+        check(lib().loco_op_gemm_f16x3_splitk(ptr(ahi), ptr(alo), K, ptr(whi), ptr(wlo), K, ptr(bd), ptr(Rd) if epi == 2 else None, N,
+                                              None if out_split else ptr(C_), ptr(chi) if out_split else None,
+                                              ptr(clo) if out_split else None, N, M, N, K, epi, ptr(ws), ws.numel(), stream()))
+        return (chi.float() + clo.float()) if out_split else C_
+
+    out = run()
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 1:
+        ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+    if epi == 2:
+        ref = ref + R.double()
+    assert rel_l2(out, ref) < 5e-6
+    assert torch.equal(out, run())

@@ -4,6 +4,9 @@ import importlib, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 la = importlib.import_module("loco-asr_amd")
+if len(sys.argv) > 1:  # profile another build of the library (A/B runs inside one gpurun call)
+    la._lib.LIB_PATH = os.path.abspath(sys.argv[1])
+    print("library:", la._lib.LIB_PATH)
 sd = la.synth.encoder_state_dict(0)
 pre, enc_sd = la.synth.split_state_dict(sd)
 m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()}, {k: torch.from_numpy(v) for k, v in enc_sd.items()}).to("cuda")
