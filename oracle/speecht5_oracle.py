@@ -18,6 +18,10 @@ structure where HF cannot scale: the relative-position bias is evaluated in its 
 ``bias[i,j] = (q_i . pe_k^T)[clip(i-j,-160,159)+160]`` and attention runs over query blocks, so
 10-minute inputs (T = 29 999; HF would need a 230 GB ``[T,T,64]`` table) stay feasible.
 
+The text branch of the same scripts (`…base…py:79-93`: ``model.speecht5.encoder(texts.input_ids)``) is restated by
+``text_prenet`` / ``encode_text`` (HF ``SpeechT5TextEncoderPrenet``, ``SpeechT5ScaledPositionalEncoding``,
+``SpeechT5EncoderWithTextPrenet``) and pinned by fixture g6, generated from HF's own class.
+
 Pinning: the reference has no tests, so parity is pinned by fixtures generated
 in the build container from the HF implementation itself (``tests/golden/make_goldens.py``) and by
 ``tests/test_oracle_vs_hf.py`` which compares this file with the installed HF module directly
