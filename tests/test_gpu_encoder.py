@@ -247,3 +247,23 @@ def test_two_stream_half_batches_are_bit_identical():
     finally:
         enc.use_graphs = False
         enc.streams = 2
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (3, 63), (2, 64), (2, 65), (1, 127), (3, 128), (1, 129), (2, 256), (2, 257), (4, 256),
+                                 (4, 257), (1, 1023), (1, 1025), (8, 1024), (8, 1025)])
+def test_shape_sweep_around_tile_and_dispatch_boundaries(B, T, oracle):
+    """Frame counts around every size the kernels branch on: the 64-key attention tile, the 128/256-row GEMM tiles, the
+    M = 512 / 1024 / 8192 dispatch thresholds (128-row tiles, split-K), ragged masks included.  Two encoder layers, fp32
+    oracle, default precision."""
+    m, sd = model(layers=2)
+    enc = m.speecht5.encoder
+    L = 320 * T + 80
+    assert la.synth.conv_out_length(L) == T
+    lengths = [L - (173 * i * L) // (4 * max(B, 2)) // 7 * 7 for i in range(B)]  # clip 0 full length, the others shorter
+    lengths = [max(400, n) for n in lengths]
+    x, msk = la.synth.batch(lengths, first_index=T % 17)
+    y = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda()).last_hidden_state
+    assert tuple(y.shape) == (B, T, 768) and bool(torch.isfinite(y).all())
+    ref = oracle.encode(x, msk, sd)
+    assert rel_l2(y, ref) < TOL, (B, T)
+    assert enc.last_frames.tolist() == [la.synth.conv_out_length(n) for n in lengths]
