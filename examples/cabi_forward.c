@@ -1,0 +1,81 @@
+/* The drop-in boundary without Python or torch: a plain C host drives libloco_asr.so through include/loco_asr.h.
+ *
+ *   gcc examples/cabi_forward.c -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -Lloco-asr_amd -lloco_asr \
+ *       -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/loco-asr_amd -Wl,-rpath,/opt/rocm/lib -o cabi_forward
+ *   ./cabi_forward weights.bin manifest.txt wave.f32 B L out.f32
+ *
+ * manifest.txt: one line per tensor "<hf key> <ndim> <d0> [<d1> ...]" in the order the fp32 data appear in weights.bin
+ * (keys exactly as `prenet.*` / `wrapped_encoder.*` of the reference's two state dicts, include/loco_asr.h).
+ * wave.f32: B*L fp32 samples; out.f32 receives B*T*768 fp32 embeddings.  tests/test_gpu_cabi_c.py builds and runs this
+ * and compares the file with what the Python wrapper returns (bit for bit: it is the same library call).
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "loco_asr.h"
+
+#define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK_LOCO(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s: [%d] %s\n", #x, rc_, loco_last_error()); return 3; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc != 7) { fprintf(stderr, "usage: %s weights.bin manifest.txt wave.f32 B L out.f32\n", argv[0]); return 1; }
+    const int B = atoi(argv[4]);
+    const long L = atol(argv[5]);
+    if (loco_abi_version() != 1) { fprintf(stderr, "unexpected ABI version %d\n", loco_abi_version()); return 1; }
+
+    loco_config cfg;
+    loco_default_config(&cfg);
+    loco_encoder* enc = loco_create(&cfg);
+    if (!enc) { fprintf(stderr, "loco_create: %s\n", loco_last_error()); return 3; }
+
+    /* ---- weights: host buffers are fine, the library copies them to the device */
+    FILE* fw = fopen(argv[1], "rb");
+    FILE* fm = fopen(argv[2], "r");
+    if (!fw || !fm) { perror("weights/manifest"); return 1; }
+    char key[256];
+    int ndim;
+    while (fscanf(fm, "%255s %d", key, &ndim) == 2) {
+        int64_t shape[4];
+        size_t n = 1;
+        for (int i = 0; i < ndim; ++i) { long d; if (fscanf(fm, "%ld", &d) != 1) return 1; shape[i] = d; n *= (size_t)d; }
+        float* buf = (float*)malloc(n * sizeof(float));
+        if (!buf || fread(buf, sizeof(float), n, fw) != n) { fprintf(stderr, "short read for %s\n", key); return 1; }
+        CHECK_LOCO(loco_set_weight(enc, key, buf, shape, ndim));
+        free(buf);
+    }
+    fclose(fw);
+    fclose(fm);
+    char missing[512];
+    if (loco_missing_weights(enc, missing, sizeof missing)) { fprintf(stderr, "missing weights: %s\n", missing); return 3; }
+    hipStream_t stream;
+    CHECK_HIP(hipStreamCreate(&stream));
+    CHECK_LOCO(loco_finalize_weights(enc, stream));
+
+    /* ---- input, output, workspace: plain device pointers */
+    const long T = loco_output_frames(L);
+    const size_t nin = (size_t)B * L, nout = (size_t)B * T * 768;
+    float* hwav = (float*)malloc(nin * sizeof(float));
+    FILE* fx = fopen(argv[3], "rb");
+    if (!fx || fread(hwav, sizeof(float), nin, fx) != nin) { fprintf(stderr, "cannot read %s\n", argv[3]); return 1; }
+    fclose(fx);
+    float *dwav, *dout;
+    void* ws;
+    const size_t wsb = loco_workspace_bytes(enc, B, L);
+    CHECK_HIP(hipMalloc((void**)&dwav, nin * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dout, nout * sizeof(float)));
+    CHECK_HIP(hipMalloc(&ws, wsb));
+    CHECK_HIP(hipMemcpyAsync(dwav, hwav, nin * sizeof(float), hipMemcpyHostToDevice, stream));
+    CHECK_LOCO(loco_forward(enc, dwav, NULL, B, L, dout, NULL, NULL, ws, wsb, stream));
+    float* hout = (float*)malloc(nout * sizeof(float));
+    CHECK_HIP(hipMemcpyAsync(hout, dout, nout * sizeof(float), hipMemcpyDeviceToHost, stream));
+    CHECK_HIP(hipStreamSynchronize(stream));
+    FILE* fo = fopen(argv[6], "wb");
+    if (!fo || fwrite(hout, sizeof(float), nout, fo) != nout) { perror("out"); return 1; }
+    fclose(fo);
+    printf("encoded %d x %ld samples -> [%d, %ld, 768], workspace %.1f MB\n", B, L, B, T, wsb / 1e6);
+    loco_destroy(enc);
+    return 0;
+}
