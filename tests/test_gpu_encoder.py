@@ -267,3 +267,43 @@ def test_shape_sweep_around_tile_and_dispatch_boundaries(B, T, oracle):
     ref = oracle.encode(x, msk, sd)
     assert rel_l2(y, ref) < TOL, (B, T)
     assert enc.last_frames.tolist() == [la.synth.conv_out_length(n) for n in lengths]
+
+
+def test_c_abi_error_codes():
+    """What a C caller sees for bad arguments: negative codes and a message, never a crash or a silent wrong result."""
+    import ctypes as C
+
+    from gpu_util import lib, ptr, stream
+    m, _ = model(layers=1)
+    enc = m.speecht5.encoder
+    enc(input_values=torch.zeros(1, 16000, device="cuda"))  # creates + finalises the handle
+    L_ = lib()
+    h = enc._handle
+    x = torch.zeros(2, 16000, device="cuda")
+    out = torch.empty(2, 49, 768, device="cuda")
+    need = int(L_.loco_workspace_bytes(h, 2, 16000))
+    ws = torch.empty(need + 256, dtype=torch.uint8, device="cuda")
+    ok = L_.loco_forward(h, ptr(x), None, 2, 16000, ptr(out), None, None, ptr(ws), need, stream())
+    assert ok == 0
+    # workspace one byte short -> LOCO_E_WORKSPACE, message names both sizes
+    rc = L_.loco_forward(h, ptr(x), None, 2, 16000, ptr(out), None, None, ptr(ws), need - 1, stream())
+    assert rc < 0 and str(need).encode() in L_.loco_last_error()
+    # misaligned workspace
+    rc = L_.loco_forward(h, ptr(x), None, 2, 16000, ptr(out), None, None, C.c_void_p(ws.data_ptr() + 4), need, stream())
+    assert rc < 0 and b"aligned" in L_.loco_last_error()
+    # null pointers, empty batch, input shorter than one frame
+    assert L_.loco_forward(h, None, None, 2, 16000, ptr(out), None, None, ptr(ws), need, stream()) < 0
+    assert L_.loco_forward(h, ptr(x), None, 0, 16000, ptr(out), None, None, ptr(ws), need, stream()) < 0
+    assert L_.loco_forward(h, ptr(x), None, 2, 399, ptr(out), None, None, ptr(ws), need, stream()) < 0
+    assert L_.loco_workspace_bytes(h, 2, 399) == 0 and L_.loco_output_frames(399) == 0 and L_.loco_output_frames(400) == 1
+    # knobs reject values outside their domain
+    assert L_.loco_set_streams(h, 3) < 0 and L_.loco_set_streams(h, 2) == 0
+    assert L_.loco_set_precision(h, 7) < 0 and L_.loco_set_precision(h, 1) == 0
+    # an unknown weight name / a wrong shape are reported by name
+    w = torch.zeros(3, 3, device="cuda")
+    shp = (C.c_int64 * 2)(3, 3)
+    assert L_.loco_set_weight(h, b"wrapped_encoder.layers.0.nope.weight", ptr(w), shp, 2) < 0 and b"nope" in L_.loco_last_error()
+    assert L_.loco_set_weight(h, b"wrapped_encoder.layer_norm.weight", ptr(w), shp, 2) < 0 and b"size mismatch" in L_.loco_last_error()
+    # the handle still works after all of that
+    y = enc(input_values=x).last_hidden_state
+    assert torch.equal(y, out)
