@@ -466,7 +466,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     // Variant choice (tools/gemm_split_bench.py, MI355X): the LDS-DMA ring kernels win whenever there are enough rows to
     // fill 256-row tiles; the 256x256 / 16-wave form is ~5 % ahead when it still yields >= 3 full rounds of 256
     // workgroups with N a multiple of 256 (QKV, the conv layers), the 256x128 / 8-wave form otherwise; small problems
-    // (tests, short clips) take the register-staged 128x128 kernel.
+    // (M < 1024: short clips, the text branch, tests) take the 128x128 / 4-wave form at the end of this function.
     if (a.M >= 1024) {
         const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
         const int dma = (a.N % 256 == 0 && t256 >= 768) ? 2 : 1;
