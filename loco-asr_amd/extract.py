@@ -142,6 +142,9 @@ def main(argv=None):
     ap.add_argument("--do-normalize", action="store_true")
     ap.add_argument("--normalize-on-device", action="store_true",
                     help="with --do-normalize: run zero_mean_unit_var_norm on the GPU right after the H2D copy instead of in numpy")
+    ap.add_argument("--loader-threads", type=int, default=8,
+                    help="decode / synthesise the NEXT batches on this many host threads while the GPU encodes the current one "
+                         "(the reference loads inside collate_fn with num_workers=0, …base…py:53-57,67); 0 = inline")
     ap.add_argument("--text-prenet-state-dict", default="extracted/speecht5/mapping/text_prenet_state_dict.pickle")
     ap.add_argument("--tokenizer", default="microsoft/speecht5_asr",
                     help="-m text: name or local directory of the SpeechT5 tokenizer (the reference's processor, …base…py:38)")
@@ -224,12 +227,33 @@ def main(argv=None):
     shards = [dp.shard_units(lengths, world, r) if any(lengths) else list(range(r, len(items), world)) for r in range(world)]
     mine = shards[rank]
     n_rounds = (max(len(s) for s in shards) + args.batch_size - 1) // args.batch_size  # equal on all ranks: collectives line up
+    def host_batch(rnd):
+        """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads."""
+        idx = mine[rnd * args.batch_size:(rnd + 1) * args.batch_size]
+        if not idx:
+            return idx, None
+        if pool is not None and args.window_seconds <= 0:  # the window cache of one decoded recording is not thread-safe
+            clips = list(pool.map(fetch, idx))
+        else:
+            clips = [fetch(i) for i in idx]
+        return idx, processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(args.loader_threads) if args.loader_threads > 0 else None
+    stager = ThreadPoolExecutor(1) if pool is not None else None
+    ahead = 2  # batches being prepared while one is on the GPU
+    pending = [stager.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if stager else []
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
         for rnd in range(n_rounds):
-            idx = mine[rnd * args.batch_size:(rnd + 1) * args.batch_size]
+            if stager:
+                idx, feats = pending.pop(0).result()
+                if rnd + ahead < n_rounds:
+                    pending.append(stager.submit(host_batch, rnd + ahead))
+            else:
+                idx, feats = host_batch(rnd)
             emb = torch.zeros((0, 1, 768), dtype=torch.float32, device=device)
             if idx:
-                audios = processor(audio=[fetch(i) for i in idx], sampling_rate=16000, return_tensors="pt", padding="longest").to(device)
+                audios = feats.to(device)
                 emb = model.speecht5.encoder(**audios).last_hidden_state
             if args.gather and world > 1:
                 embs = dp.gather_ragged(emb, idx, len(items))  # the one large collective of the step
@@ -239,6 +263,9 @@ def main(argv=None):
                             sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
             elif idx:
                 sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+    for ex in (stager, pool):
+        if ex is not None:
+            ex.shutdown()
     print("Done!")
 
 
