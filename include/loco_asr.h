@@ -104,6 +104,9 @@ size_t loco_workspace_bytes(const loco_encoder* enc, int32_t B, int64_t L);
  *   hidden_states  NULL, or host array of layers+1 device pointers f32 [B,T,768] receiving the input of
  *                  every layer and the final output (HF output_hidden_states=True, modeling:1287-1313)
  *   workspace      >= loco_workspace_bytes(enc, B, L) bytes (device)
+ * Asynchronous: everything is enqueued on `stream` (and, for large batches, on a second stream joined back to it, see
+ * loco_set_streams); nothing is allocated and the host is never blocked.  One handle serves one host thread at a time
+ * (the reference is single-threaded, ...base...py:67-68); use one handle per thread / per GPU otherwise.
  */
 int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
