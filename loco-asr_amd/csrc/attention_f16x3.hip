@@ -12,12 +12,14 @@
 //
 // P as the next MFMA's B operand without touching LDS: the C/D fragment of S^T holds, in lane-half h, register 8s+j,
 // key 16s + 8(j>>2) + 4h + (j&3) of a 32-key sub-tile; the 32x32x16 B operand wants k = 8h + j from that lane half, so
-// registers 8s..8s+7 ARE k-step s up to a permutation of k -- the same permutation is applied to the V^T operand, which
-// therefore reads two 8-byte runs of 4 consecutive keys {16s+4h, 16s+8+4h} from a [d][key] LDS image.
+// registers 8s..8s+7 ARE k-step s up to a permutation of k.  The same permutation is baked into the V^T planes (frame t
+// sits in column vt_col(t), loco_kernels.h), so the matching A fragment is one contiguous 16-byte piece.
 //
-// LDS per stage: K planes 64 keys x (64+8) halves (144-byte rows: conflict-free ds_read_b128), V^T planes 64 d x (64+4)
-// halves (136-byte rows: conflict-free ds_read_b64); two stages + the per-wave bias transpose scratch = 78.5 KiB, two
-// workgroups per CU.
+// LDS: two-deep rings of K and V^T tiles (hi + lo planes, 64 rows x 128 bytes, unpadded: filled by LDS-DMA, 16-byte pieces
+// XOR-swizzled on the source address so that ds_read_b128 is conflict-free) = 64 KiB + the per-wave bias transpose
+// scratch = 72.5 KiB, two workgroups per CU.  The loop is software-pipelined INSIDE each wave (QK of tile t+1 against the
+// softmax of tile t, see the main loop): the chip is power-limited here, so what that buys is fewer stalls per joule, not
+// a higher matrix-pipe duty cycle at the nominal clock.
 #include "loco_kernels.h"
 
 namespace loco {
