@@ -445,10 +445,9 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
     return LOCO_OK;
 }
 
-// ---- precision 1: the GEMMs (conv layers 1-6, feature projection, QKV / out / FFN projections = 90 % of the FLOPs) on the
-// fp16 x3 split MFMA; every producer writes the fp16 hi/lo planes its consumer needs, so no separate conversion pass
-// exists.  conv0, the positional conv, the Qp table and attention stay on their fp32 kernels; residuals, LayerNorm
-// statistics and softmax stay fp32.
+// ---- precision 1: every contraction (conv layers 1-6, feature projection, positional conv, QKV / out / FFN projections, the
+// Qp table, QK^T and PV) on the fp16 x3 split MFMA; every producer writes the fp16 hi/lo planes its consumer needs, so no
+// separate conversion pass exists.  conv0 (10 taps, VALU), residuals, GroupNorm / LayerNorm statistics and softmax stay fp32.
 int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
                   hipStream_t s, bool skip_prenet = false) {
     const int B = p.B;
