@@ -93,7 +93,29 @@ hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStrea
 // kernel is not limited by the matrix pipe's power the way the GEMM is, so the simpler 32x32x16 form stays.)
 __host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// Exact (erf) GELU, HF transformers/activations.py:83-89, without erff's two divergent branches.
+//   erfc(t) = exp(-t q(t)) for t >= 0 with q(t) = -ln(erfc(t)) / t smooth and slowly varying (q(0) = 2/sqrt(pi)); with
+//   s = |x|, t = s/sqrt(2) and the 1/sqrt(2) and log2(e) factors folded into the coefficients:  e = 2^(-s Q(s)) = erfc(s/sqrt 2),
+//   GELU(x) = x (1 - e/2) for x >= 0,   x e/2 for x < 0        -- no cancellation in either branch.
+// Q: degree-9 fit of q on t in [0, 4.1] (erfc(4.1) = 6.7e-9; |x| is clamped there, GELU is x resp. 0 to 2e-8 beyond).
+// Against an fp64 GELU on [-9, 9]: relative error <= 2.2e-7 for x > 0 (torch's fp32 GELU: 3.7e-7), absolute error <= the
+// rounding of x itself; relative L2 on N(0, 1.5) inputs 2.9e-8.  10 FMAs + one v_exp_f32 instead of ~45 instructions.
+__device__ __forceinline__ float gelu_erf(float x) {
+    constexpr float kSMax = 5.79827547f;  // 4.1 * sqrt(2)
+    const float s = fminf(fabsf(x), kSMax);
+    float q = 2.171883651e-08f;
+    q = fmaf(q, s, -6.759613029e-07f);
+    q = fmaf(q, s, 9.013814633e-06f);
+    q = fmaf(q, s, -6.522983313e-05f);
+    q = fmaf(q, s, 2.421164681e-04f);
+    q = fmaf(q, s, 7.379760791e-05f);
+    q = fmaf(q, s, -7.028903347e-03f);
+    q = fmaf(q, s, 5.248807371e-02f);
+    q = fmaf(q, s, 4.592096508e-01f);
+    q = fmaf(q, s, 1.151104808e+00f);
+    const float h = 0.5f * __builtin_amdgcn_exp2f(-(q * s));  // erfc(|x| / sqrt 2) / 2
+    return x >= 0.f ? x * (1.0f - h) : fmaxf(x, -kSMax) * h;
+}
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
