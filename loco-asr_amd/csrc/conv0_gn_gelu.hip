@@ -116,28 +116,24 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     for (int i = threadIdx.x; i < nx; i += 256) xs[i] = x[i];
 
     const int c0 = threadIdx.x * 2;
-    float w0[10], w1[10];
+    f32x2_t w01[10];  // the thread's two channels side by side: conv taps, GroupNorm affine and GELU run on packed fp32 math
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        w0[k] = w[c0 * 10 + k];
-        w1[k] = w[(c0 + 1) * 10 + k];
-    }
-    const float mu0 = mean[b * kConvDim + c0], mu1 = mean[b * kConvDim + c0 + 1];
-    const float sc0 = scale[b * kConvDim + c0], sc1 = scale[b * kConvDim + c0 + 1];
-    const float be0 = gn_b[c0], be1 = gn_b[c0 + 1];
+    for (int k = 0; k < 10; ++k) w01[k] = f32x2_t{w[c0 * 10 + k], w[(c0 + 1) * 10 + k]};
+    const f32x2_t mu = {mean[b * kConvDim + c0], mean[b * kConvDim + c0 + 1]};
+    const f32x2_t sc = {scale[b * kConvDim + c0], scale[b * kConvDim + c0 + 1]};
+    const f32x2_t be = {gn_b[c0], gn_b[c0 + 1]};
     __syncthreads();
 
     const long obase = ((long)b * T0 + t0) * kConvDim + c0;
     for (int t = 0; t < nt; ++t) {
-        float y0 = 0.f, y1 = 0.f;
+        f32x2_t y = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const float xv = xs[5 * t + k];
-            y0 = fmaf(w0[k], xv, y0);
-            y1 = fmaf(w1[k], xv, y1);
+            y = __builtin_elementwise_fma(w01[k], f32x2_t{xv, xv}, y);
         }
-        float r0 = gelu_erf(fmaf(y0 - mu0, sc0, be0));
-        float r1 = gelu_erf(fmaf(y1 - mu1, sc1, be1));
+        const f32x2_t g = gelu_erf2(__builtin_elementwise_fma(y - mu, sc, be));
+        float r0 = g.x, r1 = g.y;
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
             asm volatile("" : "+v"(r0), "+v"(r1));
             h2_t hi, lo;

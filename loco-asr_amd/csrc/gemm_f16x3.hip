@@ -26,12 +26,12 @@ template <int EPI, bool OUT_SPLIT>
 __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n, int z1 = 0, int z2 = 0) {
     if (EPI == kEpiGelu) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[e], v[e + 1]}); v[e] = g_.x; v[e + 1] = g_.y; }
     }
     if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(p.R + coff + (long)m * p.ldr + n);
     if (EPI == kEpiPosConv) {  // hidden + GELU(conv + bias) + sinusoid (HF modeling:555-564); z1 = clip, z2 = group, m = frame
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[e], v[e + 1]}); v[e] = g_.x; v[e + 1] = g_.y; }
         int nvalid = p.frames ? p.frames[z1] : p.T;
         if (nvalid <= 0 || nvalid > p.T) nvalid = p.T;
         const int pos = m < nvalid ? m + 2 : 1;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+            for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[j][e], v[j][e + 1]}); v[j][e] = g_.x; v[j][e + 1] = g_.y; }
     }
     if (EPI == kEpiResidual) {
         const float* rp = p.R + coff + (long)m * p.ldr + n;

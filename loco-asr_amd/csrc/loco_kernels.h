@@ -117,6 +117,31 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x >= 0.f ? x * (1.0f - h) : fmaxf(x, -kSMax) * h;
 }
 
+// The same on two values at once: the polynomial runs on v_pk_fma_f32 (two fp32 FMAs per instruction).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    constexpr float kSMax = 5.79827547f;
+    const f32x2_t s = {fminf(fabsf(x.x), kSMax), fminf(fabsf(x.y), kSMax)};
+#define LOCO_Q2(c) (f32x2_t){(c), (c)}
+    f32x2_t q = LOCO_Q2(2.171883651e-08f);
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(-6.759613029e-07f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(9.013814633e-06f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(-6.522983313e-05f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(2.421164681e-04f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(7.379760791e-05f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(-7.028903347e-03f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(5.248807371e-02f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(4.592096508e-01f));
+    q = __builtin_elementwise_fma(q, s, LOCO_Q2(1.151104808e+00f));
+#undef LOCO_Q2
+    const f32x2_t u = q * s;
+    const f32x2_t h = {0.5f * __builtin_amdgcn_exp2f(-u.x), 0.5f * __builtin_amdgcn_exp2f(-u.y)};
+    f32x2_t r;
+    r.x = x.x >= 0.f ? x.x * (1.0f - h.x) : fmaxf(x.x, -kSMax) * h.x;
+    r.y = x.y >= 0.f ? x.y * (1.0f - h.y) : fmaxf(x.y, -kSMax) * h.y;
+    return r;
+}
+
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
                             hipStream_t s, void* yhi = nullptr, void* ylo = nullptr);
