@@ -125,24 +125,29 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     __syncthreads();
 
     const long obase = ((long)b * T0 + t0) * kConvDim + c0;
-    for (int t = 0; t < nt; ++t) {
-        f32x2_t y = {0.f, 0.f};
+    for (int t = 0; t < nt; t += 2) {  // two frames per trip: the hi/lo split works on two value pairs at a time
+        const int t1 = t + 1 < nt ? t + 1 : t;
+        f32x2_t ya = {0.f, 0.f}, yb = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            const float xv = xs[5 * t + k];
-            y = __builtin_elementwise_fma(w01[k], f32x2_t{xv, xv}, y);
+            const float xa = xs[5 * t + k], xb = xs[5 * t1 + k];
+            ya = __builtin_elementwise_fma(w01[k], f32x2_t{xa, xa}, ya);
+            yb = __builtin_elementwise_fma(w01[k], f32x2_t{xb, xb}, yb);
         }
-        const f32x2_t g = gelu_erf2(__builtin_elementwise_fma(y - mu, sc, be));
-        float r0 = g.x, r1 = g.y;
+        const f32x2_t ga = gelu_erf2(__builtin_elementwise_fma(ya - mu, sc, be));
+        const f32x2_t gb = gelu_erf2(__builtin_elementwise_fma(yb - mu, sc, be));
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
-            asm volatile("" : "+v"(r0), "+v"(r1));
-            h2_t hi, lo;
-            hi[0] = (_Float16)r0; hi[1] = (_Float16)r1;
-            lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
-            *reinterpret_cast<h2_t*>(out_hi + obase + (long)t * kConvDim) = hi;
-            *reinterpret_cast<h2_t*>(out_lo + obase + (long)t * kConvDim) = lo;
+            unsigned ha, la, hb, lb;
+            split_f16_2pairs(ga.x, ga.y, gb.x, gb.y, ha, la, hb, lb);
+            *reinterpret_cast<unsigned*>(out_hi + obase + (long)t * kConvDim) = ha;
+            *reinterpret_cast<unsigned*>(out_lo + obase + (long)t * kConvDim) = la;
+            if (t1 != t) {
+                *reinterpret_cast<unsigned*>(out_hi + obase + (long)t1 * kConvDim) = hb;
+                *reinterpret_cast<unsigned*>(out_lo + obase + (long)t1 * kConvDim) = lb;
+            }
         } else {
-            *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(r0, r1);
+            *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(ga.x, ga.y);
+            if (t1 != t) *reinterpret_cast<float2*>(out + obase + (long)t1 * kConvDim) = make_float2(gb.x, gb.y);
         }
     }
 }

@@ -44,16 +44,18 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
         *reinterpret_cast<f32x4*>(p.C + coff + (long)m * p.ldc + n) = v;
         return;
     }
-    h4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        // Pin v as a rounded fp32 value first: with fp contraction hipcc folds the producing multiply into
-        // v_fma_mix*_f16 for the lo term but converts the stored hi from the fp32-rounded product -- a
-        // double-rounding mismatch worth one fp16 ulp of hi on ties.
-        asm volatile("" : "+v"(v[e]));
-        hi[e] = (_Float16)v[e];
-        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    // hi and lo must derive from the SAME rounded fp32 value (left to itself hipcc folds the producing multiply into
+    // v_fma_mix*_f16 for lo but converts hi from the fp32-rounded product: one fp16 ulp of hi on ties); the explicit
+    // instructions of split_f16_2pairs read the value registers, which settles it.
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t hu, lu;
+    {
+        unsigned h0, l0, h1, l1;
+        split_f16_2pairs(v[0], v[1], v[2], v[3], h0, l0, h1, l1);
+        hu = u32x2_t{h0, h1};
+        lu = u32x2_t{l0, l1};
     }
+    const h4 hi = __builtin_bit_cast(h4, hu), lo = __builtin_bit_cast(h4, lu);
     if (EPI == kEpiQkvScatter) {
         if (n < kHidden) {  // q
             *reinterpret_cast<h4*>(p.Chi + (long)m * kHidden + n) = hi;
@@ -107,17 +109,19 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cp + 4 * j) = v[j];
         return;
     }
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     h8 hi[2], lo[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[j][e];
-            asm volatile("" : "+v"(x));  // see split_gemm_store: keep hi and lo derived from the same rounded fp32 value
-            const _Float16 a = (_Float16)x;
-            hi[j >> 1][4 * (j & 1) + e] = a;
-            lo[j >> 1][4 * (j & 1) + e] = (_Float16)(x - (float)a);
-        }
+    for (int jj = 0; jj < 2; ++jj) {  // v[2jj], v[2jj+1] -> one h8 of each plane
+        u32x4_t hu, lu;
+        unsigned h0, l0, h1, l1;
+        split_f16_2pairs(v[2 * jj][0], v[2 * jj][1], v[2 * jj][2], v[2 * jj][3], h0, l0, h1, l1);
+        hu[0] = h0; hu[1] = h1; lu[0] = l0; lu[1] = l1;
+        split_f16_2pairs(v[2 * jj + 1][0], v[2 * jj + 1][1], v[2 * jj + 1][2], v[2 * jj + 1][3], h0, l0, h1, l1);
+        hu[2] = h0; hu[3] = h1; lu[2] = l0; lu[3] = l1;
+        hi[jj] = __builtin_bit_cast(h8, hu);
+        lo[jj] = __builtin_bit_cast(h8, lu);
+    }
     _Float16 *dh, *dl;
     if (EPI == kEpiQkvScatter) {
         const bool isq = n < kHidden;

@@ -117,6 +117,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x >= 0.f ? x * (1.0f - h) : fmaxf(x, -kSMax) * h;
 }
 
+// fp16 hi/lo split of two value pairs (a0,a1) and (b0,b1): hi = fp16(x) (hipcc emits one v_cvt_pk_f16_f32 per pair),
+// lo = fp16(x - hi) by one mixed-precision FMA per value (fp32 x, fp16 hi: the difference is exact in fp32, so lo is
+// rounded once -- bit for bit what `lo = (_Float16)(x - (float)hi)` gives, at 6 instructions for 4 values instead of 16).
+//  * the inputs are pinned first: left to itself hipcc folds the producing multiply into v_fma_mix*_f16 for lo but converts
+//    hi from the fp32-rounded product (one fp16 ulp of hi on ties);
+//  * hi stays compiler-visible code, so the first instruction that reads a value coming from an MFMA or from the
+//    transcendental unit is one hipcc pads itself -- it does not look inside inline asm;
+//  * inside the asm the two pairs are interleaved: each v_fma_mixhi (which merges into the register its v_fma_mixlo wrote
+//    16 bits of) has an independent instruction in front of it.
+__device__ __forceinline__ void split_f16_2pairs(float a0, float a1, float b0, float b1, unsigned& hia, unsigned& loa, unsigned& hib,
+                                                 unsigned& lob) {
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+    const h2_ ha = {(_Float16)a0, (_Float16)a1}, hb = {(_Float16)b0, (_Float16)b1};
+    hia = __builtin_bit_cast(unsigned, ha);
+    hib = __builtin_bit_cast(unsigned, hb);
+    asm("v_fma_mixlo_f16 %0, %2, 1.0, -%6 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %4, 1.0, -%7 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %3, 1.0, -%6 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, 1.0, -%7 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(loa), "=&v"(lob)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(hia), "v"(hib));
+}
+
 // The same on two values at once: the polynomial runs on v_pk_fma_f32 (two fp32 FMAs per instruction).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
