@@ -28,7 +28,16 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
 #pragma unroll
         for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[e], v[e + 1]}); v[e] = g_.x; v[e + 1] = g_.y; }
     }
-    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(p.R + coff + (long)m * p.ldr + n);
+    if (EPI == kEpiResidual) {
+        const long ro = coff + (long)m * p.ldr + n;
+        if (p.Rhi) {
+            const h4 rh = *reinterpret_cast<const h4*>(p.Rhi + ro), rl = *reinterpret_cast<const h4*>(p.Rlo + ro);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rh[e] + (float)rl[e];
+        } else {
+            v += *reinterpret_cast<const f32x4*>(p.R + ro);
+        }
+    }
     if (EPI == kEpiPosConv) {  // hidden + GELU(conv + bias) + sinusoid (HF modeling:555-564); z1 = clip, z2 = group, m = frame
 #pragma unroll
         for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[e], v[e + 1]}); v[e] = g_.x; v[e + 1] = g_.y; }
@@ -99,9 +108,18 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
             for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[j][e], v[j][e + 1]}); v[j][e] = g_.x; v[j][e + 1] = g_.y; }
     }
     if (EPI == kEpiResidual) {
-        const float* rp = p.R + coff + (long)m * p.ldr + n;
+        const long ro = coff + (long)m * p.ldr + n;
+        if (p.Rhi) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] += *reinterpret_cast<const f32x4*>(rp + 4 * j);
+            for (int jj = 0; jj < 2; ++jj) {
+                const h8 rh = *reinterpret_cast<const h8*>(p.Rhi + ro + 8 * jj), rl = *reinterpret_cast<const h8*>(p.Rlo + ro + 8 * jj);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[2 * jj + (e >> 2)][e & 3] += (float)rh[e] + (float)rl[e];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += *reinterpret_cast<const f32x4*>(p.R + ro + 4 * j);
+        }
     }
     if (!OUT_SPLIT && EPI != kEpiQkvScatter) {
         float* cp = p.C + coff + (long)m * p.ldc + n;
@@ -413,7 +431,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % SBK != 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.sA1 | a.sA2) & 7) return hipErrorInvalidValue;  // 16-byte staging of 8 halves
     if ((a.N | a.ldc | a.sC1 | a.sC2) & 3) return hipErrorInvalidValue;
-    if (a.epilogue == kEpiResidual && (!a.R || (a.ldr & 3))) return hipErrorInvalidValue;
+    if (a.epilogue == kEpiResidual && ((!a.R && !(a.Rhi && a.Rlo)) || (a.ldr & (a.Rhi ? 7 : 3)))) return hipErrorInvalidValue;
     const bool split = a.Chi != nullptr;
     if (split ? (a.Clo == nullptr) : (a.C == nullptr)) return hipErrorInvalidValue;
     if (a.epilogue == kEpiQkvScatter &&

@@ -289,8 +289,10 @@ int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const
 int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
                    const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
                    int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0, int nb2 = 1, long sA2 = 0, long sC2 = 0,
-                   const GemmSplitArgs* scatter = nullptr) {
+                   const GemmSplitArgs* scatter = nullptr, const _Float16* Rhi = nullptr, const _Float16* Rlo = nullptr) {
     GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epi};
+    a.Rhi = Rhi;
+    a.Rlo = Rlo;
     if (scatter) {
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
         a.T = scatter->T; a.Tp = scatter->Tp;
@@ -310,6 +312,8 @@ int make_split(SplitW& w, const float* src, size_t n, hipStream_t s) {
     HIP_TRY(launch_split_f16(src, w.hi, w.lo, (long)n, s));
     return LOCO_OK;
 }
+
+bool nl_is_zero(const loco_encoder* e) { return e->cfg.layers == 0; }
 
 int run_copy(loco_encoder* e, hipStream_t s, float* dst, const float* src, size_t n) {
     Bracket br(e, s, K_COPY, 0.0, 8.0 * n);
@@ -550,7 +554,11 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     _Float16 *chi, *clo, *fhi, *flo;
     planes(bf.ctx, (size_t)M * kHidden, chi, clo);
     planes(bf.ffn, (size_t)M * e->cfg.ffn, fhi, flo);
-    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0, M, kHidden, x0hi, x0lo))) return rc;
+    // Between layers the residual stream exists only as its fp16 hi/lo planes (22 bits): they are what the next GEMM reads
+    // as its A operand anyway, and the residual adds reconstruct hi + lo exactly.  An fp32 copy is written only where
+    // somebody reads one: hidden-state outputs, the zero-layer configuration, and the final output.
+    float* x0f = (hidden_states || nl_is_zero(e)) ? x0 : nullptr;
+    if ((rc = run_ln(e, s, x0, W(e, we + "layer_norm.weight"), W(e, we + "layer_norm.bias"), x0f, M, kHidden, x0hi, x0lo))) return rc;
     const int nl = e->cfg.layers;
     for (int l = 0; l < nl; ++l) {
         if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
@@ -570,19 +578,20 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
             HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
                                            Tp, s));
         }
-        if ((rc = run_gemm_split(e, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), x0, kHidden, tmp, nullptr,
-                                 nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual)))
+        if ((rc = run_gemm_split(e, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), nullptr, kHidden, tmp, nullptr,
+                                 nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x0hi, x0lo)))
             return rc;
-        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), x1, M, kHidden, x1hi, x1lo))) return rc;
+        if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), nullptr, M, kHidden, x1hi, x1lo))) return rc;
         if ((rc = run_gemm_split(e, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
                                  nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu)))
             return rc;
-        if ((rc = run_gemm_split(e, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), x1, kHidden,
-                                 tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual)))
+        if ((rc = run_gemm_split(e, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), nullptr, kHidden,
+                                 tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x1hi,
+                                 x1lo)))
             return rc;
         const bool last = l == nl - 1;
-        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"), last ? out : x0, M, kHidden,
-                         last ? nullptr : x0hi, last ? nullptr : x0lo)))
+        if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"),
+                         last ? out : (hidden_states ? x0 : nullptr), M, kHidden, last ? nullptr : x0hi, last ? nullptr : x0lo)))
             return rc;
     }
     if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;

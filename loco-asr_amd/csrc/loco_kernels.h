@@ -59,6 +59,10 @@ struct GemmSplitArgs {
     // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
     // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp],
     // frame t in column vt_col(t)
+    // kEpiResidual: the residual may also be given as fp16 hi/lo planes (same element offsets and ldr as R); it is then hi + lo,
+    // exact in fp32.  The encoder's residual stream lives only in that form between layers (LayerNorm writes no fp32 copy).
+    const _Float16* Rhi = nullptr;
+    const _Float16* Rlo = nullptr;
     // split-K for small problems (launch_gemm_split decides): fp32 partial sums [ks][M][N], >= kSplitKBytes when set
     float* splitk_ws = nullptr;
     _Float16* Khi = nullptr;

@@ -52,15 +52,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         o[3] = v[i].w * rstd * gg.w + bb.w;
         if (y) reinterpret_cast<float4*>(y + row * D)[lane + 64 * i] = make_float4(o[0], o[1], o[2], o[3]);
         if (SPLIT) {
-            h4_t hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                asm volatile("" : "+v"(o[e]));  // one fp32 rounding before the split (see gemm_f16x3.hip epilogue)
-                hi[e] = (_Float16)o[e];
-                lo[e] = (_Float16)(o[e] - (float)hi[e]);
-            }
-            reinterpret_cast<h4_t*>(yhi + row * D)[lane + 64 * i] = hi;
-            reinterpret_cast<h4_t*>(ylo + row * D)[lane + 64 * i] = lo;
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            unsigned h0, l0, h1, l1;
+            split_f16_2pairs(o[0], o[1], o[2], o[3], h0, l0, h1, l1);
+            reinterpret_cast<u32x2_t*>(yhi + row * D)[lane + 64 * i] = u32x2_t{h0, h1};
+            reinterpret_cast<u32x2_t*>(ylo + row * D)[lane + 64 * i] = u32x2_t{l0, l1};
         }
     }
 }
