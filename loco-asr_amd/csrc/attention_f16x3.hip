@@ -361,17 +361,14 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 c[e] = o1[4 * g4 + e] * inv;
             }
             if (OUT_SPLIT) {
-                h4 ah, al, ch, cl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    asm volatile("" : "+v"(a[e]), "+v"(c[e]));
-                    ah[e] = (_Float16)a[e]; al[e] = (_Float16)(a[e] - (float)ah[e]);
-                    ch[e] = (_Float16)c[e]; cl[e] = (_Float16)(c[e] - (float)ch[e]);
-                }
-                *reinterpret_cast<h4*>(ctx_hi + obase + 8 * g4) = ah;
-                *reinterpret_cast<h4*>(ctx_lo + obase + 8 * g4) = al;
-                *reinterpret_cast<h4*>(ctx_hi + obase + 32 + 8 * g4) = ch;
-                *reinterpret_cast<h4*>(ctx_lo + obase + 32 + 8 * g4) = cl;
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                unsigned h0, l0, h1, l1;
+                split_f16_2pairs(a[0], a[1], a[2], a[3], h0, l0, h1, l1);
+                *reinterpret_cast<u32x2*>(ctx_hi + obase + 8 * g4) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(ctx_lo + obase + 8 * g4) = u32x2{l0, l1};
+                split_f16_2pairs(c[0], c[1], c[2], c[3], h0, l0, h1, l1);
+                *reinterpret_cast<u32x2*>(ctx_hi + obase + 32 + 8 * g4) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(ctx_lo + obase + 32 + 8 * g4) = u32x2{l0, l1};
             } else {
                 *reinterpret_cast<float4*>(ctx + obase + 8 * g4) = make_float4(a[0], a[1], a[2], a[3]);
                 *reinterpret_cast<float4*>(ctx + obase + 32 + 8 * g4) = make_float4(c[0], c[1], c[2], c[3]);
