@@ -863,12 +863,13 @@ int64_t loco_output_frames(int64_t n) {
 namespace {
 // Two half-batches on two streams: clips are independent, so the halves give the same bits as one pass, and the tail of
 // every kernel of one half (the last, partly filled round of workgroups: up to 12 % of the N = 768 GEMMs) is filled by
-// the other half's kernels.  Worth it only while each half still fills the chip for several rounds per kernel.
+// the other half's kernels.  Measured gain (tools/two_stream_probe.py): +2 % at 32 x 30 s, +5..8 % at 16-32 clips of 2.5-15 s;
+// halves of fewer than ~1000 frames (8 x 5 s) lose 4 %, so those stay on one stream.
 bool split_batch(const loco_encoder* e, int B, long L, Plan& p0, Plan& p1) {
     if (e->streams < 2 || B < 2) return false;
     const int B0 = (B + 1) / 2;
     if (!make_plan(e, B0, L, p0) || !make_plan(e, B - B0, L, p1)) return false;
-    return p1.M >= 16384;
+    return p1.M >= 1024;
 }
 }  // namespace
 

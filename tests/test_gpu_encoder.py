@@ -217,7 +217,7 @@ def test_two_stream_half_batches_are_bit_identical():
     calls that reuse the workspace, and hipGraph capture of the fork/join included."""
     m, _ = model(layers=2)
     enc = m.speecht5.encoder
-    lens = [480000 - 1731 * i for i in range(23)]  # 23 clips of ~30 s: 12 + 11, each half >= 16384 frames
+    lens = [480000 - 1731 * i for i in range(23)]  # 23 clips of ~30 s: 12 + 11 (halves of >= 1024 frames run on two streams)
     x, msk = la.synth.batch(lens)
     xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
     enc.streams = 1

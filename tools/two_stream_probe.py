@@ -8,7 +8,8 @@ sd = la.synth.encoder_state_dict(0)
 pre, enc_sd = la.synth.split_state_dict(sd)
 m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()}, {k: torch.from_numpy(v) for k, v in enc_sd.items()}).to("cuda")
 enc = m.speecht5.encoder
-for B, secs, reps in ((32, 30.0, 8), (4, 600.0, 3), (16, 30.0, 8)):
+SHAPES = ((32, 30.0, 8), (4, 600.0, 3), (16, 30.0, 8)) if len(sys.argv) < 2 else ((2, 5.0, 40), (4, 5.0, 40), (8, 5.0, 30), (8, 2.5, 30), (6, 10.0, 30))
+for B, secs, reps in SHAPES:
     x, msk = la.synth.batch([int(secs * 16000)] * B)
     xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
     for rnd in range(2):
