@@ -116,38 +116,40 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     for (int i = threadIdx.x; i < nx; i += 256) xs[i] = x[i];
 
     const int c0 = threadIdx.x * 2;
-    f32x2_t w01[10];  // the thread's two channels side by side: conv taps, GroupNorm affine and GELU run on packed fp32 math
+    float w0[10], w1[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) w01[k] = f32x2_t{w[c0 * 10 + k], w[(c0 + 1) * 10 + k]};
-    const f32x2_t mu = {mean[b * kConvDim + c0], mean[b * kConvDim + c0 + 1]};
-    const f32x2_t sc = {scale[b * kConvDim + c0], scale[b * kConvDim + c0 + 1]};
-    const f32x2_t be = {gn_b[c0], gn_b[c0 + 1]};
+    for (int k = 0; k < 10; ++k) {
+        w0[k] = w[c0 * 10 + k];
+        w1[k] = w[(c0 + 1) * 10 + k];
+    }
+    const float mu0 = mean[b * kConvDim + c0], mu1 = mean[b * kConvDim + c0 + 1];
+    const float sc0 = scale[b * kConvDim + c0], sc1 = scale[b * kConvDim + c0 + 1];
+    const float be0 = gn_b[c0], be1 = gn_b[c0 + 1];
     __syncthreads();
 
     const long obase = ((long)b * T0 + t0) * kConvDim + c0;
-    for (int t = 0; t < nt; t += 2) {  // two frames per trip: the hi/lo split works on two value pairs at a time
-        const int t1 = t + 1 < nt ? t + 1 : t;
-        f32x2_t ya = {0.f, 0.f}, yb = {0.f, 0.f};
+    for (int t = 0; t < nt; ++t) {
+        float y0 = 0.f, y1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            const float xa = xs[5 * t + k], xb = xs[5 * t1 + k];
-            ya = __builtin_elementwise_fma(w01[k], f32x2_t{xa, xa}, ya);
-            yb = __builtin_elementwise_fma(w01[k], f32x2_t{xb, xb}, yb);
+            const float xv = xs[5 * t + k];
+            y0 = fmaf(w0[k], xv, y0);
+            y1 = fmaf(w1[k], xv, y1);
         }
-        const f32x2_t ga = gelu_erf2(__builtin_elementwise_fma(ya - mu, sc, be));
-        const f32x2_t gb = gelu_erf2(__builtin_elementwise_fma(yb - mu, sc, be));
+        // The ten taps stay scalar FMAs on purpose.  A version with the two channels packed (v_pk_fma_f32 on the taps) gave
+        // sporadically different values in the first clips of a batch -- only while kernels of another stream were resident
+        // on the same CUs (tools/race_probe.py: 6-11 of 12 trials; this form: 0 of 40).  Not understood; not used.
+        const f32x2_t g_ = gelu_erf2(f32x2_t{fmaf(y0 - mu0, sc0, be0), fmaf(y1 - mu1, sc1, be1)});
+        float r0 = g_.x, r1 = g_.y;
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
-            unsigned ha, la, hb, lb;
-            split_f16_2pairs(ga.x, ga.y, gb.x, gb.y, ha, la, hb, lb);
-            *reinterpret_cast<unsigned*>(out_hi + obase + (long)t * kConvDim) = ha;
-            *reinterpret_cast<unsigned*>(out_lo + obase + (long)t * kConvDim) = la;
-            if (t1 != t) {
-                *reinterpret_cast<unsigned*>(out_hi + obase + (long)t1 * kConvDim) = hb;
-                *reinterpret_cast<unsigned*>(out_lo + obase + (long)t1 * kConvDim) = lb;
-            }
+            asm volatile("" : "+v"(r0), "+v"(r1));
+            h2_t hi, lo;
+            hi[0] = (_Float16)r0; hi[1] = (_Float16)r1;
+            lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
+            *reinterpret_cast<h2_t*>(out_hi + obase + (long)t * kConvDim) = hi;
+            *reinterpret_cast<h2_t*>(out_lo + obase + (long)t * kConvDim) = lo;
         } else {
-            *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(ga.x, ga.y);
-            if (t1 != t) *reinterpret_cast<float2*>(out + obase + (long)t1 * kConvDim) = make_float2(gb.x, gb.y);
+            *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(r0, r1);
         }
     }
 }

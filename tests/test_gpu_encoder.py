@@ -307,3 +307,43 @@ def test_c_abi_error_codes():
     # the handle still works after all of that
     y = enc(input_values=x).last_hidden_state
     assert torch.equal(y, out)
+
+
+def test_concurrent_forwards_on_two_user_streams_are_bit_identical():
+    """A C caller may enqueue independent forwards of one handle on different streams (from one host thread).  Two half
+    batches on two streams, three steps back to back with no synchronisation in between -- so that one stream's front-end
+    kernels share CUs with the other's late-layer kernels -- must reproduce the single pass bit for bit, every time.
+    (Regression: a packed-math variant of the conv0 kernel did not; tools/race_probe.py is the stand-alone form.)"""
+    import ctypes as C
+
+    from gpu_util import lib
+    m, _ = model()
+    enc = m.speecht5.encoder
+    B, L = 32, 480000
+    x, msk = la.synth.batch([L] * B)
+    xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda().int()
+    enc.streams = 1
+    try:
+        ref = enc(input_values=xs, attention_mask=ms).last_hidden_state
+        L_, h = lib(), enc._handle
+        L_.loco_set_streams(h, 1)
+        T = int(L_.loco_output_frames(L))
+        need = int(L_.loco_workspace_bytes(h, B // 2, L))
+        wss = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        out = torch.empty(B, T, 768, device="cuda")
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        for trial in range(8):
+            out.zero_()
+            torch.cuda.synchronize()
+            for _ in range(3):
+                for i in range(2):
+                    a, b = i * (B // 2), (i + 1) * (B // 2)
+                    rc = L_.loco_forward(h, C.c_void_p(xs[a:b].data_ptr()), C.c_void_p(ms[a:b].data_ptr()), b - a, L,
+                                         C.c_void_p(out[a:b].data_ptr()), None, None, C.c_void_p(wss[i].data_ptr()), need,
+                                         C.c_void_p(streams[i].cuda_stream))
+                    assert rc == 0, L_.loco_last_error()
+            torch.cuda.synchronize()
+            bad = [i for i in range(B) if not torch.equal(out[i], ref[i])]
+            assert not bad, (trial, bad)
+    finally:
+        enc.streams = 2
