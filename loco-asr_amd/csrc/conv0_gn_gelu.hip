@@ -138,7 +138,10 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         }
         // The ten taps stay scalar FMAs on purpose.  A version with the two channels packed (v_pk_fma_f32 on the taps) gave
         // sporadically different values in the first clips of a batch -- only while kernels of another stream were resident
-        // on the same CUs (tools/race_probe.py: 6-11 of 12 trials; this form: 0 of 40).  Not understood; not used.
+        // on the same CUs (tools/race_probe.py: 6-11 of 12 trials; this form: 0 of 40).  hipcc had compiled those taps to
+        // IN-PLACE packed FMAs whose destination pair is also the source read with an op_sel cross-selection
+        // (`v_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]`); no other kernel of this library contains that
+        // form (tests/test_isa_patterns.py keeps it that way).
         const f32x2_t g_ = gelu_erf2(f32x2_t{fmaf(y0 - mu0, sc0, be0), fmaf(y1 - mu1, sc1, be1)});
         float r0 = g_.x, r1 = g_.y;
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
