@@ -150,7 +150,8 @@ int loco_get_precision(const loco_encoder* enc);
 /* Concurrency inside one loco_forward.  n = 2 (default): a batch whose halves each hold >= 1024 frames runs as two
  * half-batches, the second on a stream the encoder owns, forked from and joined back to `stream` with events (so the
  * call still behaves as one in-order operation on `stream`, also under stream capture).  Clips are independent, so the
- * output is bit-identical to n = 1; the gain (2-8 %, largest for mid-size batches) is the other half's kernels filling
+ * output is bit-identical to n = 1 for halves of more than 8192 frames, and equal up to the fp32 summation order of the
+ * split-K GEMM path (<= 4e-6 relative, still run-to-run deterministic) below that; the gain (2-8 %, largest for mid-size batches) is the other half's kernels filling
  * each kernel's last, partly filled round of workgroups.  loco_workspace_bytes covers both modes.  Profiling, hidden states and taps use n = 1. */
 int loco_set_streams(loco_encoder* enc, int n);
 

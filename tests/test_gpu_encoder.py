@@ -347,3 +347,23 @@ def test_concurrent_forwards_on_two_user_streams_are_bit_identical():
             assert not bad, (trial, bad)
     finally:
         enc.streams = 2
+
+
+def test_two_streams_on_a_mid_size_batch():
+    """16 x 5 s: halves of 1992 frames take the split-K GEMM path with other K slices than the whole batch would, so the two
+    schedules agree to fp32 summation order, not bit for bit; each is deterministic and within the parity bar."""
+    m, sd = model()
+    enc = m.speecht5.encoder
+    lens = [80000 - 997 * i for i in range(16)]
+    x, msk = la.synth.batch(lens)
+    xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
+    try:
+        enc.streams = 1
+        one = enc(input_values=xs, attention_mask=ms).last_hidden_state
+        enc.streams = 2
+        two = enc(input_values=xs, attention_mask=ms).last_hidden_state
+        again = enc(input_values=xs, attention_mask=ms).last_hidden_state
+        assert torch.equal(two, again)
+        assert rel_l2(two, one) < 5e-6
+    finally:
+        enc.streams = 2

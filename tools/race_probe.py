@@ -9,7 +9,7 @@ pre, enc_sd = la.synth.split_state_dict(sd)
 m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()}, {k: torch.from_numpy(v) for k, v in enc_sd.items()}).to("cuda")
 enc = m.speecht5.encoder
 lib = enc._lib
-B, secs = 32, 30.0
+B, secs = (32, 30.0) if len(sys.argv) < 3 else (int(sys.argv[1]), float(sys.argv[2]))
 x, msk = la.synth.batch([int(secs * 16000)] * B)
 xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda().int()
 enc.streams = 1
@@ -17,8 +17,8 @@ ref = enc(input_values=xs, attention_mask=ms).last_hidden_state
 if hasattr(lib, "loco_set_streams"):
     lib.loco_set_streams(enc._handle, 1)
 L = xs.shape[1]; T = int(lib.loco_output_frames(L)); h = enc._handle
-cuts = [0, 16, 32]
-wss = [torch.empty(int(lib.loco_workspace_bytes(h, 16, L)) + (1 << 20), dtype=torch.uint8, device="cuda") for i in range(2)]
+cuts = [0, B // 2, B]
+wss = [torch.empty(int(lib.loco_workspace_bytes(h, B // 2, L)) + (1 << 20), dtype=torch.uint8, device="cuda") for i in range(2)]
 guard = torch.zeros(1 << 22, dtype=torch.uint8, device="cuda")
 out = torch.empty(B, T, 768, device="cuda")
 streams = [torch.cuda.Stream() for _ in range(2)]
