@@ -1,9 +1,10 @@
-"""Weight import: fairseq SpeechT5-base checkpoint keys -> the two HuggingFace-named state dicts the encoder loads.
+"""Weight import: fairseq SpeechT5-base checkpoint keys -> the three HuggingFace-named state dicts the encoders load.
 
-Restates what the reference's `Mapping` class produces for the SPEECH path
-(/root/reference/speech_text/map_speecht5_hf.py:34-99 encoder, :101-166 speech prenet) as an explicit rename
-table instead of its nested string searches; the text-prenet dict (:168-181) is out of scope.  Inferred from the
-reference's matching rules, the fairseq names are
+Restates what the reference's `Mapping` class produces (/root/reference/speech_text/map_speecht5_hf.py:34-99 encoder,
+:101-166 speech prenet, :168-181 text prenet) as explicit rename tables instead of its nested string searches.  The tables
+are pinned by tests/golden/g9_mapping.json, which tests/golden/make_mapping_goldens.py wrote by running THE REFERENCE'S
+`Mapping` itself on a synthetic fairseq-named checkpoint and locally instantiated HF models (tests/test_host_logic.py).
+The fairseq names are
 
     encoder.pos_emb.pe_k.weight                                   -> embed_positions.pe_k.weight
     encoder.layer_norm.{weight,bias}                              -> layer_norm.*
@@ -18,9 +19,11 @@ reference's matching rules, the fairseq names are
     speech_encoder_prenet.feature_extractor.conv_layers.N.2.*     -> feature_encoder.conv_layers.N.layer_norm.*
     speech_encoder_prenet.pos_conv.0.{bias,weight_g,weight_v}     -> pos_conv_embed.conv.{bias,weight_g,weight_v}
 
-(`weight_g/weight_v` is the transformers-4.30.2 spelling; the encoder's load_state_dict accepts it and the 5.x
-`parametrizations.weight.original0/1` spelling alike.)  No checkpoint is reachable offline, so this module is
-verified by round-tripping the synthetic state dict through the inverse rename (tests/test_host_logic.py).
+    text_encoder_prenet.encoder_prenet.0.weight                   -> embed_tokens.weight            (text prenet dict)
+
+(`weight_g/weight_v` is the transformers-4.30.2 spelling, the reference's pin; the encoder's load_state_dict accepts it and
+the 5.x `parametrizations.weight.original0/1` spelling alike.  Run against transformers 5.x the reference's own rule for
+those two keys finds no partner and silently drops them -- recorded in the fixture's "hf_installed" table.)
 """
 from __future__ import annotations
 
@@ -73,6 +76,23 @@ def map_fairseq_speecht5(ckpt_model: Dict[str, object]) -> Tuple[Dict[str, objec
             else:
                 pre[nk] = v
     return enc, pre, unmapped
+
+
+def map_text_prenet(ckpt_model: Dict[str, object], tts_prenet_state: Dict[str, object] | None = None) -> Dict[str, object]:
+    """The reference's third dict (map_speecht5_hf.py:168-181): ``embed_tokens.weight`` is taken from the fairseq checkpoint
+    (``text_encoder_prenet.encoder_prenet.0.weight``); every other entry -- ``encode_positions.alpha`` and the sinusoid
+    buffer ``encode_positions.pe`` -- is copied from the HF TTS model's text prenet (``tts_prenet_state`` =
+    ``model_tts.speecht5.encoder.prenet.state_dict()`` plus its ``encode_positions.pe`` buffer), NOT from the checkpoint.
+    Without an HF model at hand (``tts_prenet_state=None``) alpha falls back to the fairseq value
+    ``text_encoder_prenet.encoder_prenet.1.alpha`` when present and ``pe`` is left out (the library generates the table)."""
+    out = {"embed_tokens.weight": ckpt_model["text_encoder_prenet.encoder_prenet.0.weight"]}
+    if tts_prenet_state is not None:
+        for k, v in tts_prenet_state.items():
+            if k != "embed_tokens.weight":
+                out[k] = v
+    elif "text_encoder_prenet.encoder_prenet.1.alpha" in ckpt_model:
+        out["encode_positions.alpha"] = ckpt_model["text_encoder_prenet.encoder_prenet.1.alpha"]
+    return out
 
 
 def to_fairseq_names(prenet_sd: Dict[str, object], encoder_sd: Dict[str, object]) -> Dict[str, object]:

@@ -14,6 +14,8 @@
 // no VALU on conversion.  One kernel template (gemm_f16x3_dma_kernel, below) covers every shape: 256x256, 256x128 and
 // 128x128 tiles on an LDS ring filled by LDS-DMA, 64x64 per wave, D = W_tile * A_tile^T orientation; small problems add
 // split-K with a fixed-order reduction (launch_gemm_split).
+#include <cstdlib>
+
 #include "loco_kernels.h"
 
 namespace loco {
@@ -174,9 +176,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // MF16: issue v_mfma_f32_16x16x32_f16 (16 accumulators of 16x16 per wave) instead of 32x32x16 (4 of 32x32): same FLOPs,
 // LDS bytes and registers, but the chip sustains a higher clock on that shape when the matrix pipes are the power draw.
 // NJ: 16-column sub-tiles each wave actually computes (4, or 3 when N = 48: the positional conv's 48 outputs per group).
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m, int tiles_n,
-                                                                                      int nblk) {
+// WPS: waves per SIMD the register allocation must leave room for (0 = one workgroup per CU: (WM * WN) / 4).  The two-per-CU
+// forms (192x128 / 6 waves and 128x128 / 4 waves, two-stage rings of 80 / 64 KiB) exist so that one workgroup's epilogue
+// (GELU + plane split on the VALU, 64-256 KiB of stores draining to HBM) runs under the OTHER workgroup's main loop.
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4, int WPS = 0>
+__global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
+                                                                                                  int tiles_n, int nblk) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
     constexpr int DPA = DBM * SBK, DPW = DBN * SBK;  // halves per A / W plane
     constexpr int DBUF = 2 * DPA + 2 * DPW;
@@ -427,6 +432,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int
     split_gemm_store<EPI, OUT_SPLIT>(p, v, 0, m, n);
 }
 
+// One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, DST ring stages, WPS as in the kernel template.
+template <int WM, int WN, int DST, int WPS>
+static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
+    constexpr int bm = 64 * WM, bn = 64 * WN;
+    const int tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn;
+    const long nb = (long)tm * tn * a.nb1 * a.nb2;
+    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+    const bool sp = a.Chi != nullptr;
+#define TILE_LAUNCH(EPI)                                                                                                              \
+    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, DST, true, 4, WPS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, s, a, \
+                               tm, tn, (int)nb);                                                                                      \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, DST, true, 4, WPS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, s, a,   \
+                            tm, tn, (int)nb);
+    switch (a.epilogue) {
+        case kEpiNone: TILE_LAUNCH(kEpiNone) break;
+        case kEpiGelu: TILE_LAUNCH(kEpiGelu) break;
+        case kEpiResidual: TILE_LAUNCH(kEpiResidual) break;
+        case kEpiQkvScatter: TILE_LAUNCH(kEpiQkvScatter) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TILE_LAUNCH
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % SBK != 0) return hipErrorInvalidValue;
     if ((a.lda | a.ldw | a.sA1 | a.sA2) & 7) return hipErrorInvalidValue;  // 16-byte staging of 8 halves
@@ -485,57 +514,28 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
     }
-    // Variant choice (tools/gemm_split_bench.py, MI355X): the LDS-DMA ring kernels win whenever there are enough rows to
-    // fill 256-row tiles; the 256x256 / 16-wave form is ~5 % ahead when it still yields >= 3 full rounds of 256
-    // workgroups with N a multiple of 256 (QKV, the conv layers), the 256x128 / 8-wave form otherwise; small problems
-    // (M < 1024: short clips, the text branch, tests) take the 128x128 / 4-wave form at the end of this function.
-    if (a.M >= 1024) {
-        const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
-        const int dma = (a.N % 256 == 0 && t256 >= 768) ? 2 : 1;
-        const int bm_ = 256, bn_ = dma == 2 ? 256 : 128;
-        const int tm = (a.M + bm_ - 1) / bm_, tn = (a.N + bn_ - 1) / bn_;
-        const long nb = (long)tm * tn * a.nb1 * a.nb2;
-        if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-        const bool sp = a.Chi != nullptr;
-        // MFMA shape: 16x16x32 measured +12..24 % over 32x32x16 on every encoder shape at identical FLOPs / LDS bytes / registers
-        // (QKV 296 -> 332, FFN1 242 -> 300, conv1 313 -> 377 TFLOP/s algorithmic): the chip holds a higher clock on it.
-        constexpr bool mf32 = false;
-#define DMA_LAUNCH2(EPI, SP, MF)                                                                                                        \
-        if (dma == 2) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, SP, 4, 4, 2, MF>), dim3((unsigned)nb), dim3(1024), 0, s, a, tm, tn, (int)nb); \
-        else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, SP, 4, 2, 3, MF>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, tn, (int)nb);
-#define DMA_LAUNCH(EPI)                                        \
-        if (sp) {                                              \
-            if (mf32) { DMA_LAUNCH2(EPI, true, false) } else { DMA_LAUNCH2(EPI, true, true) }     \
-        } else {                                               \
-            if (mf32) { DMA_LAUNCH2(EPI, false, false) } else { DMA_LAUNCH2(EPI, false, true) }   \
+    // Tile choice (tools/gemm_split_bench.py, MI355X).  LOCO_GEMM_TILE=<1..5> forces one form; it is read on every call so
+    // that a bench can A/B the forms inside one process (same device, same clocks).
+    const char* forced = getenv("LOCO_GEMM_TILE");
+    int tile = forced ? atoi(forced) : 0;
+    if (tile == 0) {
+        if (a.M >= 1024) {
+            // 256x256 / 16 waves is ~5 % ahead when it still yields >= 3 full rounds of 256 workgroups with N a multiple of 256
+            // (QKV, the conv layers); 256x128 / 8 waves otherwise
+            const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
+            tile = (a.N % 256 == 0 && t256 >= 768) ? 1 : 2;
+        } else {
+            tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
         }
-        switch (a.epilogue) {
-            case kEpiNone: DMA_LAUNCH(kEpiNone) break;
-            case kEpiGelu: DMA_LAUNCH(kEpiGelu) break;
-            case kEpiResidual: DMA_LAUNCH(kEpiResidual) break;
-            case kEpiQkvScatter: DMA_LAUNCH(kEpiQkvScatter) break;
-            default: return hipErrorInvalidValue;
-        }
-#undef DMA_LAUNCH
-#undef DMA_LAUNCH2
-        return hipGetLastError();
     }
-    // small M (short clips, the text branch, tests): the same LDS-DMA ring kernel at 128 x 128 (4 waves, 3 stages)
-    const int tm = (a.M + 127) / 128, tn = (a.N + 127) / 128;
-    const long nb = (long)tm * tn * a.nb1 * a.nb2;
-    if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-#define SM_LAUNCH(EPI)                                                                                                          \
-    if (split) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, 2, 2, 3, true, 4>), dim3((unsigned)nb), dim3(256), 0, s, a, tm, tn, (int)nb); \
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, 2, 2, 3, true, 4>), dim3((unsigned)nb), dim3(256), 0, s, a, tm, tn, (int)nb);
-    switch (a.epilogue) {
-        case kEpiNone: SM_LAUNCH(kEpiNone) break;
-        case kEpiGelu: SM_LAUNCH(kEpiGelu) break;
-        case kEpiResidual: SM_LAUNCH(kEpiResidual) break;
-        case kEpiQkvScatter: SM_LAUNCH(kEpiQkvScatter) break;
+    switch (tile) {
+        case 1: return launch_tile<4, 4, 2, 0>(a, s);
+        case 2: return launch_tile<4, 2, 3, 0>(a, s);
+        case 3: return launch_tile<3, 2, 2, 3>(a, s);
+        case 4: return launch_tile<2, 2, 2, 2>(a, s);
+        case 5: return launch_tile<2, 2, 3, 0>(a, s);
         default: return hipErrorInvalidValue;
     }
-#undef SM_LAUNCH
-    return hipGetLastError();
 }
 
 // x -> (hi, lo) fp16 planes, n % 4 == 0

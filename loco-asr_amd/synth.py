@@ -191,3 +191,27 @@ def conv_out_length(n: int) -> int:
     for k, s in zip(CONV_KERNEL, CONV_STRIDE):
         n = (n - k) // s + 1
     return n
+
+
+# ---- intent head ("next" row f-1): inputs of tests/golden/make_head_goldens.py, rebuilt bit for bit by the tests -----------
+def head_params(method: str):
+    """Initial (q [1,768], W [101,768], b [101]) of IntentClassifier for the head goldens -- q large enough that the
+    attention weights are far from uniform (the reference initialises it at 1e-3 scale, intent_classifier.py:17)."""
+    q = hashed_uniform(f"head/{method}/q", (1, HIDDEN), 5) * np.float32(0.35)
+    w = hashed_uniform(f"head/{method}/w", (101, HIDDEN), 5) * np.float32(1.0 / np.sqrt(float(HIDDEN)))
+    b = hashed_uniform(f"head/{method}/b", (101,), 5) * np.float32(0.05)
+    return q, w, b
+
+
+def head_batch(B: int, T: int, tag: str):
+    """Ragged zero-padded embeddings [B,T,768] as the reference's collate_fn builds them (pad_sequence,
+    train_classifier.py:47-51; clip 0 has full length), one-hot int64 targets [B,101], and the lengths."""
+    x = hashed_uniform(f"head/x/{tag}", (B, T, HIDDEN), 11) * np.float32(1.4)
+    u = hashed_uniform(f"head/len/{tag}", (B,), 11)
+    lens = np.clip((T * (0.35 + 0.65 * (u + 1) / 2)).astype(np.int64), 1, T)
+    lens[0] = T
+    for b in range(B):
+        x[b, lens[b]:] = 0
+    c = hashed_uniform(f"head/cls/{tag}", (B,), 11)
+    cls = np.clip(((c + 1) / 2 * 101).astype(np.int64), 0, 100)
+    return x, np.eye(101, dtype=np.int64)[cls], lens

@@ -2,8 +2,10 @@
 
 Restates /root/reference/speech_text/intent_classifier.py:4-49 (IntentClassifier) as a plain torch module with
 autograd, and one optimisation step of train_classifier.py:104-115 with torch.optim.Adam(lr 1e-3, wd 1e-4).
-Pinning: the reference has no fixtures for the head either; the restatement is twelve lines of stock torch ops and
-is checked in tests/test_intent_head_oracle.py against hand-derived gradients (finite differences)."""
+Pinning: the reference has no fixtures for the head, but its code is importable in the build container (torch only), so
+tests/golden/make_head_goldens.py ran THAT code (IntentClassifier driven as train_classifier.py:59-116 drives it) and
+committed its outputs as tests/golden/g8_intent_head.npz; tests/test_intent_head_oracle.py holds this restatement to them
+(logits, loss, every gradient, parameters after three Adam steps; <= 5e-6), and keeps the finite-difference checks."""
 import torch
 from torch import nn
 

@@ -1,6 +1,7 @@
-"""Intent head ("next" row f-1) on the GPU against its torch-autograd oracle: forward logits, loss, every gradient,
-and three Adam steps, for the three pooling methods, with zero-padded ragged batches as the reference's
-collate_fn builds them.  fp32 tolerances: 2e-5 relative on logits/loss/grads, 1e-5 on updated parameters."""
+"""Intent head ("next" row f-1) on the GPU: against fixture g8 -- written by the reference's own IntentClassifier driven as
+train_classifier.py drives it (tests/golden/make_head_goldens.py) -- and against the torch-autograd oracle on more shapes:
+forward logits, loss, every gradient, and three Adam steps, for the three pooling methods, with zero-padded ragged batches
+as the reference's collate_fn builds them.  fp32 tolerances: 2e-5 relative on logits/loss/grads, 1e-5 on updated parameters."""
 import importlib
 import sys
 
@@ -13,6 +14,33 @@ pytestmark = pytest.mark.gpu
 if torch.cuda.is_available():
     from gpu_util import la, rel_l2
     import intent_head_oracle as iho
+
+
+def head_with_g8_params(method):
+    q, w, b = la.synth.head_params(method)
+    head = la.IntentClassifierMI355X(method)
+    head.load_state_dict({"q": torch.from_numpy(q), "classifier.0.weight": torch.from_numpy(w), "classifier.0.bias": torch.from_numpy(b)})
+    return head.to("cuda")
+
+
+@pytest.mark.parametrize("method", ["average", "max", "attention"])
+def test_against_the_reference_fixture(method):
+    """The HIP head against what /root/reference/speech_text/intent_classifier.py + train_classifier.py:104-116 computed."""
+    from test_intent_head_oracle import G8, check_against_g8
+    head = head_with_g8_params(method)
+    x, target, _ = la.synth.head_batch(5, 129, "fwd")
+    xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(target).cuda()
+    assert rel_l2(head(xd), G8[f"{method}/fwd_logits"]) < 2e-5
+    loss, _, grads = head.loss_and_grads(xd, td)
+    assert abs(float(loss) - float(G8[f"{method}/fwd_loss"])) < 2e-5 * float(G8[f"{method}/fwd_loss"])
+    g = grads.cpu().numpy()
+    check_against_g8(f"{method}/grad_", g[:768], g[768:768 + 101 * 768].reshape(101, 768), g[768 + 101 * 768:], 5e-5)
+    for step in range(3):
+        x, target, _ = la.synth.head_batch(16, 180, f"adam{step}")
+        lg, _ = head.train_step(torch.from_numpy(x).cuda(), torch.from_numpy(target).cuda())
+        assert abs(float(lg) - float(G8[f"{method}/adam_losses"][step])) < 5e-5 * float(G8[f"{method}/adam_losses"][step]), step
+    sd = {k: v.cpu().numpy() for k, v in head.state_dict().items()}
+    check_against_g8(f"{method}/adam_", sd["q"], sd["classifier.0.weight"], sd["classifier.0.bias"], 1e-5)
 
 
 def make_batch(B, T, seed):

@@ -149,6 +149,36 @@ def test_fairseq_checkpoint_mapping_round_trip():
     assert unm == ["encoder.layers.0.mystery.weight"]
 
 
+def test_checkpoint_mapping_matches_the_reference_mapping_class():
+    """f-3 pinned: fixture g9 holds the key tables the reference's own `Mapping` (map_speecht5_hf.py) produced for a synthetic
+    fairseq-named checkpoint (tests/golden/make_mapping_goldens.py); the rename tables here must produce the same three dicts."""
+    import json
+    cm = importlib.import_module("loco-asr_amd.checkpoint_map")
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g9_mapping.json")))
+    ckpt = {k: ("ckpt", k) for k in g["fairseq_keys"]}  # value = where it came from
+    enc, pre, unmapped = cm.map_fairseq_speecht5(ckpt)
+    ref = g["hf_4_30_2"]  # the reference's pinned transformers spelling
+    assert {k: v[1] for k, v in enc.items()} == ref["encoder_state_dict"]
+    assert {k: v[1] for k, v in pre.items()} == ref["speech_prenet_state_dict"]
+    # keys the reference has no rule for are dropped there silently (encoder.version: `else: continue`, map_speecht5_hf.py:77;
+    # the fairseq sinusoid buffer matches no branch of map_speech_prenet); here they are reported instead
+    assert sorted(unmapped) == ["encoder.version", "speech_encoder_prenet.pos_sinusoidal_embed._float_tensor"]
+    assert ref["encoder_unmatched"] == []
+    # against transformers 5.x the reference's weight-norm rule finds no partner: exactly those two keys are missing there
+    missing = set(ref["speech_prenet_state_dict"]) - set(g["hf_installed"]["speech_prenet_state_dict"])
+    assert missing == {"pos_conv_embed.conv.weight_g", "pos_conv_embed.conv.weight_v"}
+    assert g["hf_installed"]["encoder_state_dict"] == ref["encoder_state_dict"]
+    # text prenet dict: embed_tokens from the checkpoint, alpha and pe from the HF TTS model (map_speecht5_hf.py:168-181)
+    tts = {"embed_tokens.weight": ("model", "embed_tokens.weight"), "encode_positions.alpha": ("model", "alpha"),
+           "encode_positions.pe": ("model", "pe")}
+    txt = cm.map_text_prenet(ckpt, tts)
+    want = ref["text_prenet_state_dict"]
+    assert set(txt) == set(want)
+    for k, src in want.items():
+        assert (txt[k][0] == "ckpt" and txt[k][1] == src) if src.startswith("text_encoder_prenet") else txt[k][0] == "model", k
+    assert cm.map_text_prenet(ckpt)["encode_positions.alpha"] == ("ckpt", "text_encoder_prenet.encoder_prenet.1.alpha")
+
+
 def test_window_units_for_long_recordings():
     """configs[3]: 60-minute recordings -> 10-minute windows as independent units."""
     hour, ten = 60 * 60 * 16000, 10 * 60 * 16000

@@ -6,6 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 L = importlib.import_module("loco-asr_amd._lib")
 lib = L.load()
 libs = {"main": lib}
+tiles = {}  # variant name -> LOCO_GEMM_TILE value (the library re-reads it on every launch)
+for a in sys.argv[1:]:
+    if a.startswith("--tiles="):  # e.g. --tiles=0,1,2,3,4: A/B the tile forms of gemm_f16x3.hip in this process
+        libs = {}
+        for t in a.split("=")[1].split(","):
+            libs["t" + t] = lib
+            tiles["t" + t] = t
 for a in sys.argv[1:]:
     if a.endswith(".so"):  # A/B another build inside the same process (same device, same clocks)
         alt = C.CDLL(os.path.abspath(a))
@@ -55,6 +62,8 @@ for rnd in range(6):
     for s in shapes:
         for v, lb in libs.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if v in tiles:
+                os.environ["LOCO_GEMM_TILE"] = tiles[v]
             run(*s, lb=lb); e0.record(); run(*s, lb=lb); run(*s, lb=lb); e1.record(); torch.cuda.synchronize()
             if rnd: res[(v, s[0])].append(e0.elapsed_time(e1) / 2)
 for name, m, n, k, epi, osplit in shapes:
