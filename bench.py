@@ -14,14 +14,16 @@ kernels; all K gathers complete inside the timed region.  Weak scaling: every ra
 clips.  Rank 0 prints ONE JSON line; `value` = frames encoded by all ranks / max-over-ranks time.
 
 Extra objects on the line:
-  roofline      the dominant kernel (the GEMM: 76 % of the FLOPs), algorithmic FLOPs / its summed launch time,
+  roofline      the dominant kernel = the profiling bucket with the largest summed launch time (the projection GEMM at
+                30 s x 32, attention at 10 min x 4): algorithmic FLOPs / its summed launch time,
                 measured live with HIP events on the launch stream over the timed region; peak = the dense MFMA
                 rate of the instruction it issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s; MI355X_MICROARCH.md);
                 for f16x3 the 3-MFMAs-per-product issue rate is reported beside the algorithmic fraction;
                 traffic = PMC HBM bytes when profiles/ holds them, else null.
   alt_precision the other precision mode measured for 3 steps in the same process.
   cpu_baseline  the CPU oracle (oracle/speecht5_oracle.py, torch fp32, all host cores) timed on a bounded
-                sample of the same workload (30 s clips, batch 4) on rank 0 at N = 1 -- reported, not targeted.
+                sample of the same workload (8 clips of 30 s: 1 warm-up + 3 timed passes, median) on rank 0 at
+                N = 1 -- reported, not targeted.
   embed_rel_l2  relative L2 of the GPU embeddings vs that oracle run on the sample clips (bar: 1e-3).
 """
 import argparse
@@ -41,8 +43,14 @@ CLIP_SECONDS = 30
 BATCH_PER_GPU = 32
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense fp32-input MFMA, MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
-DOMINANT = {"f32": ("gemm_f32", "gemm_f32_kernel", PEAK_F32_MFMA_TFLOPS, 1),
-            "f16x3": ("gemm_f16x3", "gemm_f16x3_dma_kernel", PEAK_F16_MFMA_TFLOPS, 3)}
+# profiling bucket (loco_api.hip kKernelNames) -> (kernel symbol, bound, peak, MFMAs issued per algorithmic product)
+BUCKETS = {"gemm_f32": ("gemm_f32_kernel", "mfma", PEAK_F32_MFMA_TFLOPS, 1),
+           "attention_f32": ("attention_kernel", "mfma", PEAK_F32_MFMA_TFLOPS, 1),
+           "pos_conv_f32": ("pos_conv_kernel", "mfma", PEAK_F32_MFMA_TFLOPS, 1),
+           "gemm_f16x3": ("gemm_f16x3_dma_kernel", "mfma", PEAK_F16_MFMA_TFLOPS, 3),
+           "attention_f16x3": ("attention_f16x3_kernel", "mfma", PEAK_F16_MFMA_TFLOPS, 3),
+           "pos_conv_f16x3_gemm": ("gemm_f16x3_dma_kernel (N = 48 form)", "mfma", PEAK_F16_MFMA_TFLOPS, 3)}
+PEAK_HBM_GBPS = 8000.0
 
 
 def host_cores() -> int:
@@ -70,11 +78,17 @@ def host_cores() -> int:
 
 
 def make_roofline(by, precision, steps):
-    """Roofline object of the dominant kernel: algorithmic FLOPs of its launches / their summed HIP-event duration."""
-    stat_name, kernel, peak, mfma_per_product = DOMINANT[precision]
-    g = by.get(stat_name)
-    if not g or g["ms"] <= 0:
+    """Roofline object of the DOMINANT kernel = the profiling bucket with the largest summed launch time in the timed region
+    (the projection GEMM at 30 s x 32, attention at 10 min x 4): algorithmic FLOPs of its launches / their summed
+    HIP-event duration against the dense MFMA peak of the instruction it issues; HBM-bound buckets against 8 TB/s."""
+    cands = {k: v for k, v in by.items() if v["ms"] > 0}
+    if not cands:
         return None
+    stat_name = max(cands, key=lambda k: cands[k]["ms"])
+    g = cands[stat_name]
+    kernel, bound, peak, mfma_per_product = BUCKETS.get(stat_name, (stat_name, "hbm", PEAK_HBM_GBPS, 1))
+    if precision == "f16x2" and stat_name in ("gemm_f16x3", "pos_conv_f16x3_gemm"):
+        mfma_per_product = 2  # the W_lo term is dropped in that mode
     traffic = None
     try:  # PMC HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
         import glob
@@ -83,9 +97,13 @@ def make_roofline(by, precision, steps):
             traffic = json.load(open(tf[-1]))["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         traffic = None
-    ach = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    r = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-         "traffic": traffic, "launches_per_step": g["launches"] / steps, "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+    if bound == "mfma":
+        ach, unit = g["flops"] / (g["ms"] * 1e-3) / 1e12, "TFLOP/s"
+    else:
+        ach, unit = g["bytes"] / (g["ms"] * 1e-3) / 1e9, "GB/s"
+    r = {"kernel": kernel, "bucket": stat_name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+         "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": g["launches"] / steps,
+         "avg_launch_ms": round(g["ms"] / g["launches"], 4), "share_of_kernel_time": round(g["ms"] / sum(v["ms"] for v in cands.values()), 3),
          "flops_per_launch_avg": g["flops"] / g["launches"], "algorithmic_bytes_per_launch_avg": g["bytes"] / g["launches"]}
     if mfma_per_product > 1:
         # the split algorithm issues 3 fp16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
@@ -93,6 +111,17 @@ def make_roofline(by, precision, steps):
         r["mfma_issued_tflops"] = round(ach * mfma_per_product, 1)
         r["mfma_issued_frac_of_peak"] = round(ach * mfma_per_product / peak, 4)
     return r
+
+
+def workload_label(clip_seconds, batch):
+    """config.workload from the arguments; the BASELINE.json config it corresponds to, if any."""
+    which = ""
+    if abs(clip_seconds - 30) < 1e-9 and batch == 32:
+        which = " (BASELINE.json configs[1])"
+    elif abs(clip_seconds - 600) < 1e-9 and batch == 4:
+        which = " (BASELINE.json configs[2])"
+    return (f"SpeechT5-base speech encoder, synthetic 16 kHz {clip_seconds:g} s clips, batch {batch} per GPU{which}, "
+            "random-init weights")
 
 
 def flops_per_clip(T: int) -> float:
@@ -107,14 +136,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--clip-seconds", type=float, default=CLIP_SECONDS)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU)
-    ap.add_argument("--precision", choices=["f32", "f16x3"], default="f16x3",
+    ap.add_argument("--precision", choices=["f32", "f16x3", "f16x2"], default="f16x3",
                     help="contraction arithmetic: f16x3 = three fp16 MFMAs per fp32-class product (default; 3.5e-6 rel L2 of fp64), "
                          "f32 = exact fp32 MFMA (2.3e-6), ~2x slower")
     ap.add_argument("--no-alt", action="store_true", help="skip the short measurement of the other precision mode")
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the short un-profiled run of the library's default schedule (two half-batches on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-clips", type=int, default=4)
+    ap.add_argument("--cpu-sample-clips", type=int, default=8,
+                    help="clips of the same workload the CPU oracle is timed on (1 warm-up + --cpu-reps timed passes, median)")
+    ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -178,6 +209,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert gathered.shape[0] == world * B
+    # the default range policy ("fp32": re-run out-of-range batches on the exact-fp32 kernels) was active; a re-run inside the
+    # timed region would make `value` a mixed-precision figure -- refuse to report one
+    if enc.last_range_fallback:
+        raise SystemExit("bench.py: the synthetic batch left the f16x3 activation range and was re-run in fp32 -- not a valid f16x3 measurement")
     stats = enc.profile_read()
     enc.set_profiling(False)
     if world > 1:
@@ -202,33 +237,35 @@ def main():
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16x3 (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)" if args.precision == "f16x3" else "f32",
-            "precision": args.precision, "data": "synthetic",
-            "config": {"workload": f"SpeechT5-base speech encoder, synthetic 16 kHz {args.clip_seconds:g} s clips, batch {B} per GPU "
-                                   "(BASELINE.json configs[1]), random-init weights",
+            "dtype": {"f16x3": "f16x3 (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "f32": "f32",
+                      "f16x2": "f16x2 (weights rounded to fp16, activations hi+lo, 2 MFMAs per product; opt-in, ~4e-4)"}[args.precision],
+            "precision": args.precision, "range_policy": enc.range_policy, "data": "synthetic",
+            "config": {"workload": workload_label(args.clip_seconds, B),
                        "clip_seconds": args.clip_seconds, "batch_per_gpu": B, "global_batch": B * world, "frames_per_clip": T,
                        "parallelism": f"dp{world}", "collective": "all_gather(embeddings)" if world > 1 else "none"},
             "whole_path_tflops": round(whole, 2),
             "roofline": roofline, "kernels": kernels,
         }
-        # the other precision mode, short run (3 steps), for reference
+        # the other precision modes, short runs (3 steps), for reference: the exact-fp32 mode ("alt_precision") and the opt-in
+        # two-term mode ("opt_in_precision": weights rounded to fp16, ~4e-4 instead of ~1e-6 -- never what `value` reports)
         if world == 1 and not args.no_alt:
-            alt = "f32" if args.precision == "f16x3" else "f16x3"
-            enc.precision = alt
-            enc(input_values=x, attention_mask=m)
-            torch.cuda.synchronize()
-            enc.set_profiling(True)
-            enc.profile_reset()
-            t1 = time.perf_counter()
-            for _ in range(3):
+            for key, alt in (("alt_precision", "f32" if args.precision != "f32" else "f16x3"),
+                             ("opt_in_precision", "f16x2" if args.precision != "f16x2" else "f16x3")):
+                enc.precision = alt
                 enc(input_values=x, attention_mask=m)
-            torch.cuda.synchronize()
-            ealt = time.perf_counter() - t1
-            st_alt = {s_["name"]: s_ for s_ in enc.profile_read()}
-            enc.set_profiling(False)
-            enc.precision = args.precision
-            result["alt_precision"] = {"precision": alt, "value": round(B * T * 3 / ealt, 1), "unit": "frames/s",
-                                       "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3)}
+                torch.cuda.synchronize()
+                enc.set_profiling(True)
+                enc.profile_reset()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    enc(input_values=x, attention_mask=m)
+                torch.cuda.synchronize()
+                ealt = time.perf_counter() - t1
+                st_alt = {s_["name"]: s_ for s_ in enc.profile_read()}
+                enc.set_profiling(False)
+                enc.precision = args.precision
+                result[key] = {"precision": alt, "value": round(B * T * 3 / ealt, 1), "unit": "frames/s",
+                               "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3)}
         # The timed region above runs with per-kernel HIP events, which keep loco_forward on ONE stream.  Without them the
         # library's default for big batches is two half-batches on two streams (bit-identical output, loco_set_streams):
         # the same workload, un-profiled, for reference.  `value` stays the single-stream figure the roofline belongs to.
@@ -259,7 +296,7 @@ def main():
             oracle.encode(xs[:1, :16000 * 2], None, sd)  # warm-up (thread pool, weight conversion caches)
             reps = []
             ref = None
-            for _ in range(2):
+            for _ in range(max(1, args.cpu_reps)):
                 t1 = time.perf_counter()
                 ref = oracle.encode(xs, ms, sd)
                 reps.append(time.perf_counter() - t1)
@@ -269,7 +306,9 @@ def main():
             result["cpu_baseline"] = {"value": round(nc * T / cpu_s, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
                                       "kind": "port",
                                       "sample": f"{nc} clips x {args.clip_seconds:g} s (batch {nc}) of the same synthetic workload, "
-                                                f"median of 2 runs, {cpu_s:.2f} s each, torch {torch.__version__} fp32"}
+                                                f"1 warm-up + median of {len(reps)} timed passes ({', '.join(f'{r:.2f}' for r in reps)} s), "
+                                                f"{torch.get_num_threads()} torch threads, torch {torch.__version__} fp32",
+                                      "clips": nc, "reps": len(reps)}
             result["embed_rel_l2"] = rel
             result["speedup_vs_cpu_baseline"] = round(value / (nc * T / cpu_s), 1)
         print(json.dumps(result), flush=True)

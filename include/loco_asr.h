@@ -38,7 +38,8 @@ enum {
     LOCO_E_INVALID = -1,   /* bad argument (shape, null pointer, unknown key) -- HF raises ValueError here */
     LOCO_E_STATE = -2,     /* weights missing / not finalized */
     LOCO_E_WORKSPACE = -3, /* workspace too small */
-    LOCO_E_HIP = -4        /* a HIP runtime call failed */
+    LOCO_E_HIP = -4,       /* a HIP runtime call failed */
+    LOCO_E_RANGE = -5      /* an activation left the range precision mode f16x3 represents (loco_forward_status) */
 };
 
 /* Model hyper-parameters = transformers SpeechT5Config defaults (configuration_speecht5.py:142-199),
@@ -111,6 +112,52 @@ size_t loco_workspace_bytes(const loco_encoder* enc, int32_t B, int64_t L);
 int loco_forward(loco_encoder* enc, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
                  float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
                  size_t workspace_bytes, void* stream);
+
+/* ---- numeric range of precision mode f16x3 (the default, loco_set_precision) -----------------------------------------------
+ * In that mode every GEMM operand is carried as two fp16 planes, hi = fp16(x) and lo = fp16(x - hi): 22 significant bits
+ * while lo is a normal fp16 number, an ABSOLUTE error floor of 2^-25 below that, and hi = inf from |x| >= 65520 on.
+ *   Weights are immune: at loco_finalize_weights each tensor is stored as W * 2^k, k chosen so that max|W| lands in
+ *     [2^13, 2^14), and the GEMM undoes the power of two exactly -- checkpoints with weights of 1e-7 or of 1e+4 load alike.
+ *   Activations are guaranteed to fp32 class (<= 2e-5 relative L2 of an fp64 evaluation, tests/test_gpu_range.py) as long as
+ *     the LARGEST element of every tensor that is stored as planes -- conv-stack outputs, LayerNorm outputs, q|k|v, the
+ *     attention context, the GELU'd feed-forward intermediate -- lies in [2^-6, 65504).  Every producing kernel folds
+ *     max|x| of what it writes (taken on the fp32 value, before conversion) into a status word of its stage; the words
+ *     follow the forward to host memory on its stream.
+ * loco_forward itself is asynchronous and therefore cannot know; after the stream has completed it,
+ *   loco_forward_status   returns LOCO_OK, or LOCO_E_RANGE with a message naming the first stage outside the range and its
+ *                         max|x| (also copied to `buf` when given).  In that case the output may hold inf / NaN (overflow) or
+ *                         be less accurate than fp32 class (underflow) and must not be used.
+ *   loco_forward_range    reads one stage's max|x| (diagnostics); returns the number of stages of the last forward.
+ *   loco_forward_checked  = loco_forward + hipStreamSynchronize + loco_forward_status, and, under the default policy 1, a
+ *                         second pass of the same batch on the exact-fp32 MFMA kernels of this library (precision mode 0,
+ *                         ~2.5x slower, no range limit beyond fp32's own) when the first left the range; *used_fp32 tells.
+ *                         With loco_set_range_policy(enc, 0) it returns LOCO_E_RANGE instead.  This is the entry point
+ *                         the Python module calls: a caller never sees NaNs caused by the fp16 planes.
+ * Inputs that contain inf / NaN themselves propagate as in HF (they are not a range error of this library). */
+int loco_forward_status(loco_encoder* enc, char* buf, size_t buflen);
+int loco_forward_range(const loco_encoder* enc, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen);
+int loco_set_range_policy(loco_encoder* enc, int policy);
+int loco_forward_checked(loco_encoder* enc, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
+                         float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
+                         size_t workspace_bytes, void* stream, int32_t* used_fp32);
+
+/* ---- sample-rate conversion to 16 kHz ("next" row f-4) ---------------------------------------------------------------------
+ * The reference resamples every file on the host with librosa.load(path, sr=16000)
+ * (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:56; librosa 0.10.0.post2 -> soxr 0.3.5 'soxr_hq',
+ * requirements.txt:63,138).  soxr's source is not part of the reference, so what is implemented is its published 'HQ'
+ * specification -- linear phase, pass band to 0.913 of the lower Nyquist frequency, stop band from 1.0, >= 120 dB -- as one
+ * Kaiser-windowed-sinc polyphase filter with librosa's output length ceil(n * 16000 / sr_in).  PARITY UNPINNED against
+ * librosa itself (expected agreement ~1e-5 relative: the two designs' ripple); pinned against an fp64 restatement of this
+ * specification and design-independent properties (tests/test_gpu_resample.py).
+ *   loco_resample_design  up/down = 16000/sr_in in lowest terms, taps per phase (multiple of 4); with taps_host != NULL also
+ *                         writes the [up][taps_per_phase] fp32 table to HOST memory (designed in fp64; upload it once per rate)
+ *   loco_resample_length  ceil(n_in * up / down)
+ *   loco_op_resample      y[b, n] for n < n_out <= loco_resample_length(n_in); x f32 [B, x_stride >= n_in], zero-extended
+ *                         beyond both ends; taps_dev = the table in device memory (16-byte aligned); HBM-bound, one launch. */
+int loco_resample_design(int32_t sr_in, int32_t sr_out, int32_t* up, int32_t* down, int32_t* taps_per_phase, float* taps_host);
+int64_t loco_resample_length(int64_t n_in, int32_t up, int32_t down);
+int loco_op_resample(const float* x, int32_t B, int64_t n_in, int64_t x_stride, const float* taps_dev, int32_t up, int32_t down,
+                     int32_t taps_per_phase, float* y, int64_t n_out, int64_t y_stride, void* stream);
 
 /* ---- waveform normaliser ("next" row f-4): SpeechT5FeatureExtractor(do_normalize=True) on the device -------------------
  * HF feature_extraction_speecht5.py:119-138 (the reference's collate_fn reaches it through processor(audio=...),

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libloco_asr.so")
+# LOCO_ASR_LIB: load another build of the SAME library instead (A/B and regression probes under tools/); never a fallback
+LIB_PATH = os.environ.get("LOCO_ASR_LIB") or os.path.join(_HERE, "libloco_asr.so")
 ABI_VERSION = 1
 
 
@@ -43,6 +44,13 @@ SIGNATURES = {
     "loco_output_frames": (_i64, [_i64]),
     "loco_workspace_bytes": (_sz, [_vp, _i32, _i64]),
     "loco_forward": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_forward_status": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "loco_forward_range": (C.c_int, [_vp, _i32, C.POINTER(_f), C.POINTER(_i32), C.c_char_p, _sz]),
+    "loco_set_range_policy": (C.c_int, [_vp, C.c_int]),
+    "loco_forward_checked": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_i32)]),
+    "loco_resample_design": (C.c_int, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
+    "loco_resample_length": (_i64, [_i64, _i32, _i32]),
+    "loco_op_resample": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "loco_normalize_scratch_bytes": (_sz, [_i32]),
     "loco_op_normalize_waveform": (C.c_int, [_vp, _vp, _i32, _i64, C.c_float, _vp, _vp, _sz, _vp]),
     "loco_text_workspace_bytes": (_sz, [_vp, _i32, _i32]),

@@ -25,7 +25,8 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // Shared epilogue.  v = 4 consecutive output columns n..n+3 of row m (already bias-added).
 template <int EPI, bool OUT_SPLIT>
-__device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n, int z1 = 0, int z2 = 0) {
+__device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v, long coff, int m, int n, float& amax, int z1 = 0,
+                                                 int z2 = 0) {
     if (EPI == kEpiGelu) {
 #pragma unroll
         for (int e = 0; e < 4; e += 2) { const f32x2_t g_ = gelu_erf2(f32x2_t{v[e], v[e + 1]}); v[e] = g_.x; v[e + 1] = g_.y; }
@@ -59,6 +60,7 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
     // v_fma_mix*_f16 for lo but converts hi from the fp32-rounded product: one fp16 ulp of hi on ties); the explicit
     // instructions of split_f16_2pairs read the value registers, which settles it.
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));  // range tracking (loco_kernels.h)
     u32x2_t hu, lu;
     {
         unsigned h0, l0, h1, l1;
@@ -95,12 +97,13 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
 // lane such a run (see the W-row permutation there), so planes are written as 16-byte pieces and a row's four lanes
 // complete whole 128-byte lines instead of 8-byte fragments.
 template <int EPI, bool OUT_SPLIT>
-__device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4 (&v)[4], long coff, int m, int n, int z1, int z2) {
+__device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4 (&v)[4], long coff, int m, int n, float& amax, int z1,
+                                                   int z2) {
     constexpr bool wide_epi = EPI == kEpiNone || EPI == kEpiGelu || EPI == kEpiResidual || EPI == kEpiQkvScatter;
     if (!wide_epi || n + 16 > p.N || (EPI == kEpiQkvScatter && n >= 2 * kHidden)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (n + 4 * j < p.N) split_gemm_store<EPI, OUT_SPLIT>(p, v[j], coff, m, n + 4 * j, z1, z2);
+            if (n + 4 * j < p.N) split_gemm_store<EPI, OUT_SPLIT>(p, v[j], coff, m, n + 4 * j, amax, z1, z2);
         return;
     }
     if (EPI == kEpiGelu) {
@@ -131,6 +134,8 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
     }
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     h8 hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[j][0]), fabsf(v[j][1]))), fmaxf(fabsf(v[j][2]), fabsf(v[j][3])));
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {  // v[2jj], v[2jj+1] -> one h8 of each plane
         u32x4_t hu, lu;
@@ -179,7 +184,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // WPS: waves per SIMD the register allocation must leave room for (0 = one workgroup per CU: (WM * WN) / 4).  The two-per-CU
 // forms (192x128 / 6 waves and 128x128 / 4 waves, two-stage rings of 80 / 64 KiB) exist so that one workgroup's epilogue
 // (GELU + plane split on the VALU, 64-256 KiB of stores draining to HBM) runs under the OTHER workgroup's main loop.
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4, int WPS = 0>
+// TERMS: 3 = A_hi W_hi + A_lo W_hi + A_hi W_lo (fp32 class, the default);  2 = A_hi W_hi + A_lo W_hi, i.e. the weights rounded
+// to fp16 (after their per-tensor power-of-two scale: 11 significant bits at every level) and the activations kept hi + lo --
+// the opt-in precision mode "f16x2": no W_lo plane is streamed, a third fewer MFMAs, ~4e-4 relative L2 end to end.
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4, int WPS = 0, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
                                                                                                   int tiles_n, int nblk) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
@@ -188,10 +196,11 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     constexpr int NDA = DBM / 16 / NW_;                                // 16-row DMA pieces per wave per A plane
     constexpr int NDW = (DBN / 16 + NW_ - 1) / NW_;                    // ... per W plane (the last waves may have none)
     constexpr int WPIECES = DBN / 16;
-    constexpr int NDMA = 2 * NDA + 2 * NDW;                            // DMA instructions per wave per k-tile
+    constexpr int NDMA = 2 * NDA + (TERMS == 3 ? 2 : 1) * NDW;        // DMA instructions per wave per k-tile
     static_assert(NDA >= 1, "tile too small for the wave count");
     static_assert(WPIECES % NW_ == 0 || DSTAGES == 2, "uneven W pieces need the 2-stage ring (vmcnt(0) waits only)");
     static_assert(NJ == 4 || MF16, "NJ < 4 is implemented for the 16x16x32 path");
+    static_assert(TERMS == 3 || (TERMS == 2 && MF16), "the two-term form is implemented for the 16x16x32 path");
     // PERMW: the 16 W rows (output columns) fed to MFMA sub-tile j are {16 q + 4 j + e}, q, e = 0..3, instead of 16 j .. 16 j + 15.
     // The accumulator of lane quad q4 then holds columns 16 q4 + 4 j + e: over j = 0..3 one lane owns 16 CONSECUTIVE
     // columns of its row, which the epilogue writes as 16-byte pieces (split_gemm_store16).  Same FLOPs and LDS bytes;
@@ -252,11 +261,12 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         _Pragma("unroll") for (int u = 0; u < NDW; ++u) if (WPIECES % NW_ == 0 || NDW * wave + u < WPIECES) {             \
             __builtin_amdgcn_global_load_lds((gptr_t)(p.Whi + gw[u] + (long)(kt) * SBK),                                  \
                                              (lptr_t)(b_ + 2 * DPA + 16 * (NDW * wave + u) * SBK), 16, 0, 0);             \
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Wlo + gw[u] + (long)(kt) * SBK),                                  \
-                                             (lptr_t)(b_ + 2 * DPA + DPW + 16 * (NDW * wave + u) * SBK), 16, 0, 0);       \
+            if (TERMS == 3)                                                                                               \
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.Wlo + gw[u] + (long)(kt) * SBK),                              \
+                                                 (lptr_t)(b_ + 2 * DPA + DPW + 16 * (NDW * wave + u) * SBK), 16, 0, 0);   \
         }                                                                                                                 \
     }
-#define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
     f32x16 acc[2][2];   // 32x32x16 form
     f32x4 acc16[4][NJ];  // 16x16x32 form
@@ -329,13 +339,13 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + (PERMW ? 4 : 16) * j * SBK);
-                wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + (PERMW ? 4 : 16) * j * SBK);
+                if (TERMS == 3) wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + (PERMW ? 4 : 16) * j * SBK);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc16[i][j], 0, 0, 0);
+                    if (TERMS == 3) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc16[i][j], 0, 0, 0);
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc16[i][j], 0, 0, 0);
                     acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc16[i][j], 0, 0, 0);
                 }
@@ -360,22 +370,29 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #undef DMA_ISSUE
 #undef DMA_WAIT_PENDING
 
+    // Epilogue.  The accumulators hold 2^k times the product (the weight planes are pre-scaled, GemmSplitArgs::out_scale):
+    // one exact multiply restores it.  amax = max|x| of what this lane writes into fp16 planes (range tracking).
+    const float osc = p.out_scale;
+    float amax = 0.f;
+    const unsigned seen = (OUT_SPLIT || EPI == kEpiQkvScatter) ? range_peek(p.range_slot) : 0u;  // early: its latency hides below
     if (PERMW) {
         // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 q4 + 4 j + e]
         const int n = n0 + wn * 64 + 16 * q4;
-        if (n >= p.N) return;
+        if (n < p.N) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + 16 * i + r16;
-            if (m >= p.M) continue;
-            f32x4 v[4];
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + 16 * i + r16;
+                if (m >= p.M) continue;
+                f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc16[i][j];
-                if (p.bias && n + 4 * j < p.N) v[j] += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n + 4 * j);
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc16[i][j] * osc;
+                    if (p.bias && n + 4 * j < p.N) v[j] += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n + 4 * j);
+                }
+                split_gemm_store16<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
             }
-            split_gemm_store16<EPI, OUT_SPLIT>(p, v, coff, m, n, z1, z2);
         }
+        range_commit(p.range_slot, amax, seen);
         return;
     }
     if (MF16) {
@@ -388,12 +405,13 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * 64 + 16 * j + 4 * q4;
                 if (n < p.N) {
-                    f32x4 v = acc16[i][j];
+                    f32x4 v = acc16[i][j] * osc;
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, z1, z2);
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
                 }
             }
         }
+        if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
         return;
     }
 #pragma unroll
@@ -408,13 +426,14 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
                 if (n < p.N) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * osc;
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n);
+                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax);
                 }
             }
         }
     }
+    if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
 }
 
 // Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns.
@@ -422,18 +441,23 @@ template <int EPI, bool OUT_SPLIT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int ks) {
     const long n4 = (long)p.M * (p.N / 4);
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    const int m = (int)(i / (p.N / 4));
-    const int n = 4 * (int)(i - (long)m * (p.N / 4));
-    const float* part = p.splitk_ws + (long)m * p.N + n;
-    f32x4 v = *reinterpret_cast<const f32x4*>(part);
-    for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (long)k * p.M * p.N);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-    split_gemm_store<EPI, OUT_SPLIT>(p, v, 0, m, n);
+    float amax = 0.f;
+    const unsigned seen = (OUT_SPLIT || EPI == kEpiQkvScatter) ? range_peek(p.range_slot) : 0u;
+    if (i < n4) {
+        const int m = (int)(i / (p.N / 4));
+        const int n = 4 * (int)(i - (long)m * (p.N / 4));
+        const float* part = p.splitk_ws + (long)m * p.N + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part);
+        for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (long)k * p.M * p.N);
+        v *= p.out_scale;  // the partial sums carry the weight planes' 2^k
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        split_gemm_store<EPI, OUT_SPLIT>(p, v, 0, m, n, amax);
+    }
+    if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);  // every lane of the wave gets here
 }
 
 // One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, DST ring stages, WPS as in the kernel template.
-template <int WM, int WN, int DST, int WPS>
+template <int WM, int WN, int DST, int WPS, int TERMS = 3>
 static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     constexpr int bm = 64 * WM, bn = 64 * WN;
     const int tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn;
@@ -441,10 +465,10 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     const bool sp = a.Chi != nullptr;
 #define TILE_LAUNCH(EPI)                                                                                                              \
-    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, DST, true, 4, WPS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, s, a, \
-                               tm, tn, (int)nb);                                                                                      \
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, DST, true, 4, WPS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, s, a,   \
-                            tm, tn, (int)nb);
+    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, DST, true, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, \
+                               s, a, tm, tn, (int)nb);                                                                                \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, DST, true, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0,  \
+                            s, a, tm, tn, (int)nb);
     switch (a.epilogue) {
         case kEpiNone: TILE_LAUNCH(kEpiNone) break;
         case kEpiGelu: TILE_LAUNCH(kEpiGelu) break;
@@ -472,8 +496,12 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         const int tm = (a.M + 511) / 512;
         const long nb = (long)tm * a.nb1 * a.nb2;
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
-                           (int)nb);
+        if (a.terms == 2)
+            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
+                               (int)nb);
+        else
+            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
+                               (int)nb);
         return hipGetLastError();
     }
     // Split-K for grids that cannot fill the chip (one 5 s utterance: M = 249 -> 12 workgroups for the FFN's second GEMM,
@@ -490,7 +518,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             GemmSplitArgs b = a;
             const int kslice = a.K / ks;
             b.splitk_ws = nullptr;
-            b.bias = nullptr; b.R = nullptr; b.Chi = nullptr; b.Clo = nullptr;
+            b.bias = nullptr; b.R = nullptr; b.Chi = nullptr; b.Clo = nullptr; b.out_scale = 1.0f; b.range_slot = nullptr;
             b.C = a.splitk_ws; b.ldc = a.N;
             b.nb1 = 1; b.nb2 = ks; b.sA1 = 0; b.sC1 = 0;
             b.sA2 = kslice; b.sW2 = kslice; b.sC2 = (long)a.M * a.N; b.sBias2 = 0;
@@ -524,8 +552,20 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             // (QKV, the conv layers); 256x128 / 8 waves otherwise
             const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
             tile = (a.N % 256 == 0 && t256 >= 768) ? 1 : 2;
+            const char* narrow = getenv("LOCO_GEMM_TILE_NARROW");  // A/B knob for the N <= 768 GEMMs (out-proj, FFN2, projection, Qp)
+            if (tile == 2 && narrow) tile = atoi(narrow);
         } else {
             tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
+        }
+    }
+    if (a.terms == 2) {  // precision mode "f16x2": the weights' lo plane is neither streamed nor multiplied
+        switch (tile) {
+            case 1: return launch_tile<4, 4, 2, 0, 2>(a, s);
+            case 2: return launch_tile<4, 2, 3, 0, 2>(a, s);
+            case 4: return launch_tile<2, 2, 2, 2, 2>(a, s);
+            case 3:
+            case 5: return launch_tile<2, 2, 3, 0, 2>(a, s);
+            default: return hipErrorInvalidValue;
         }
     }
     switch (tile) {
@@ -539,9 +579,9 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
 }
 
 // x -> (hi, lo) fp16 planes, n % 4 == 0
-__global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long n4) {
+__global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, long n4, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * scale;
         h4 a, b;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -555,8 +595,10 @@ __global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restri
 
 // x [B,T,768] -> group-major hi/lo planes [B][16][T+128][48] with 64 zero frames of halo on both sides
 __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int T,
-                                         long total4) {
+                                         long total4, float* __restrict__ range_slot) {
     const int rows = T + kPosK;
+    float amax = 0.f;
+    const unsigned seen = range_peek(range_slot);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % (kPosCg / 4));
         long rest = i / (kPosCg / 4);
@@ -570,18 +612,20 @@ __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* 
         h4 a, c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
+            amax = fmaxf(amax, fabsf(v[e]));
             a[e] = (_Float16)v[e];
             c[e] = (_Float16)(v[e] - (float)a[e]);
         }
         reinterpret_cast<h4*>(hi)[i] = a;
         reinterpret_cast<h4*>(lo)[i] = c;
     }
+    range_commit(range_slot, amax, seen);
 }
 
-hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s) {
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot) {
     if (B <= 0 || T <= 0) return hipErrorInvalidValue;
     const long total4 = (long)B * kPosGroups * (T + kPosK) * (kPosCg / 4);
-    hipLaunchKernelGGL(group_major_split_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, T, total4);
+    hipLaunchKernelGGL(group_major_split_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, T, total4, range_slot);
     return hipGetLastError();
 }
 
@@ -604,9 +648,9 @@ hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s) {
+hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s, float scale) {
     if (n <= 0 || (n & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, n / 4);
+    hipLaunchKernelGGL(split_f16_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, n / 4, scale);
     return hipGetLastError();
 }
 

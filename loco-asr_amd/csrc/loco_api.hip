@@ -10,6 +10,7 @@
 // past its reserved rows, mirrors HF's own auto-grow at modeling:331-333 and is done before any launch).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -55,9 +56,10 @@ struct Tensor {
 const int kConvK[7] = {10, 3, 3, 3, 3, 2, 2};
 const int kConvS[7] = {5, 2, 2, 2, 2, 2, 2};
 
-struct SplitW {  // fp16 hi/lo planes of one GEMM weight (precision mode f16x3)
+struct SplitW {  // fp16 hi/lo planes of one GEMM weight (precision mode f16x3), holding W * 2^k; inv_scale = 2^-k
     _Float16* hi = nullptr;
     _Float16* lo = nullptr;
+    float inv_scale = 1.0f;
 };
 
 struct LayerW {
@@ -66,9 +68,13 @@ struct LayerW {
     SplitW sqkv, so, s1, s2;
 };
 
-enum KernelId { K_GEMM = 0, K_ATTN, K_LN, K_CONV0, K_POSCONV, K_FRAMES, K_COPY, K_GEMM_SPLIT, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"gemm_f32",     "attention_f32", "layernorm", "conv0_gn_gelu",
-                                           "pos_conv_f32", "frame_counts",  "copy",      "gemm_f16x3"};
+// Profiling buckets, named after the kernel that runs in them (the two precision modes have their own attention and
+// positional-conv buckets: the f16x3 positional conv IS a gemm_f16x3_dma_kernel launch, but keeps a bucket of its own because
+// its shape -- N = 48, K = 6144, halo layout -- has little in common with the projection GEMMs).
+enum KernelId { K_GEMM = 0, K_ATTN, K_LN, K_CONV0, K_POSCONV, K_FRAMES, K_COPY, K_GEMM_SPLIT, K_ATTN_SPLIT, K_POSCONV_SPLIT, K_QP, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"gemm_f32",     "attention_f32", "layernorm",       "conv0_gn_gelu",
+                                           "pos_conv_f32", "frame_counts",  "copy",            "gemm_f16x3",
+                                           "attention_f16x3", "pos_conv_f16x3_gemm", "qp_table_gemm_f16x3"};
 
 struct ProfRec {
     hipEvent_t a, b;
@@ -91,7 +97,7 @@ struct loco_encoder {
     SplitW proj_s;                 // feature projection
     SplitW pe_s;                   // relative-position table pe_k [320,64]
     SplitW posg_s;                 // positional conv weight as the GEMM's W: [16][48][128*48]
-    int precision = 1;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA (default)
+    int precision = 1;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA (default), 2 = f16x2 (weights rounded to fp16; opt-in)
     std::vector<LayerW> layers;
     float* sin_tab = nullptr;
     int sin_rows = 0;
@@ -110,6 +116,17 @@ struct loco_encoder {
     int streams = 2;
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // range tracking of the fp16-plane activations (loco_kernels.h, range_commit): one status word x 8 shards per stage
+    float* range_dev = nullptr;   // [kRangeMaxStages][kRangeShards], zeroed at the start of every forward
+    float* range_host = nullptr;  // pinned copy made at the end of every forward (valid once the stream has got there)
+    float* absmax_dev = nullptr;  // one float, weight preparation
+    int range_used = 0;           // stages the last forward filled
+    const char* range_names[kRangeMaxStages] = {nullptr};
+    int range_layer[kRangeMaxStages] = {0};
+    int range_policy = 1;         // loco_forward_checked: 1 = re-run out-of-range batches on the exact-fp32 kernels, 0 = report
+    std::string range_static;     // non-empty: a weight-determined plane tensor (LayerNorm / GroupNorm output) leaves the range
+    float gn_gmax = 0.f, gn_bmax = 0.f;  // conv0 GroupNorm affine: its bound depends on the frames per clip, checked per forward
+    std::string range_forward;    // the same, for the part that depends on the input length (conv0)
     // profiling
     bool profiling = false;
     std::vector<ProfRec> recs;
@@ -289,10 +306,14 @@ int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const
 int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
                    const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
                    int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0, int nb2 = 1, long sA2 = 0, long sC2 = 0,
-                   const GemmSplitArgs* scatter = nullptr, const _Float16* Rhi = nullptr, const _Float16* Rlo = nullptr) {
+                   const GemmSplitArgs* scatter = nullptr, const _Float16* Rhi = nullptr, const _Float16* Rlo = nullptr,
+                   float* range_slot = nullptr, int kid = K_GEMM_SPLIT) {
     GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epi};
     a.Rhi = Rhi;
     a.Rlo = Rlo;
+    a.out_scale = Wt.inv_scale;
+    a.range_slot = range_slot;
+    a.terms = (e->precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
         a.T = scatter->T; a.Tp = scatter->Tp;
@@ -301,15 +322,63 @@ int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _F
     const double nb = (double)nb1 * nb2;
     const double flops = 2.0 * M * (double)N * K * nb;
     const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
-    Bracket br(e, s, K_GEMM_SPLIT, flops, bytes);
+    Bracket br(e, s, kid, flops, bytes);
     HIP_TRY(launch_gemm_split(a, s));
     return LOCO_OK;
 }
 
-int make_split(SplitW& w, const float* src, size_t n, hipStream_t s) {
+// Weight planes: W * 2^k with k such that max|W| lands in [2^13, 2^14) -- the largest element then sits two binades under
+// fp16's maximum and elements down to 2^-27 of it still have a normal fp16 lo part, whatever the tensor's absolute level
+// (a checkpoint with weights of 1e-6 or of 1e+3 is represented exactly as well as one with weights of 0.03).  The GEMM
+// multiplies its accumulator by inv_scale = 2^-k (exact).  One tiny reduction + one host read per tensor, at load time only.
+int make_split(loco_encoder* e, SplitW& w, const float* src, size_t n, hipStream_t s) {
     if (!w.hi) HIP_TRY(hipMalloc(&w.hi, n * sizeof(_Float16)));
     if (!w.lo) HIP_TRY(hipMalloc(&w.lo, n * sizeof(_Float16)));
-    HIP_TRY(launch_split_f16(src, w.hi, w.lo, (long)n, s));
+    HIP_TRY(hipMemsetAsync(e->absmax_dev, 0, sizeof(float), s));
+    HIP_TRY(launch_absmax(src, (long)n, e->absmax_dev, s));
+    float amax = 0.f;
+    HIP_TRY(hipMemcpyAsync(&amax, e->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int k = 0;
+    if (amax > 0.f && amax < INFINITY) {
+        int ex = 0;
+        (void)frexpf(amax, &ex);  // amax = f * 2^ex, f in [0.5, 1)  ->  amax * 2^(14 - ex) in [2^13, 2^14)
+        k = 14 - ex;
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    }
+    w.inv_scale = ldexpf(1.0f, -k);
+    HIP_TRY(launch_split_f16(src, w.hi, w.lo, (long)n, s, ldexpf(1.0f, k)));
+    return LOCO_OK;
+}
+
+int absmax_host(loco_encoder* e, const float* src, size_t n, hipStream_t s, float& out) {
+    HIP_TRY(hipMemsetAsync(e->absmax_dev, 0, sizeof(float), s));
+    HIP_TRY(launch_absmax(src, (long)n, e->absmax_dev, s));
+    HIP_TRY(hipMemcpyAsync(&out, e->absmax_dev, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LOCO_OK;
+}
+
+constexpr float kRangeHi = 65504.0f;   // fp16 maximum: hi = fp16(x) is inf from 65520 on
+constexpr float kRangeLo = 0.015625f;  // 2^-6: a plane tensor whose LARGEST element is below this has lost fp32-class accuracy
+
+// Plane tensors whose range follows from the weights: y = x_hat * gamma + beta with sum(x_hat^2) <= D gives
+// |y| <= sqrt(D) max|gamma| + max|beta| (LayerNorm over D channels; conv0's GroupNorm over D = frames of the clip, GELU only
+// shrinks it), and a unit-variance x_hat puts the tensor's largest element near max(max|gamma|, max|beta|).  The attention
+// context is a convex combination of V rows, tracked with q|k|v.  Checked once per weight load; nothing is measured at run time.
+int static_range_check(loco_encoder* e, const std::string& ln_prefix, int dim, hipStream_t s) {
+    float g = 0.f, b = 0.f;
+    int rc = absmax_host(e, W(e, ln_prefix + "weight"), (size_t)dim, s, g);
+    if (!rc) rc = absmax_host(e, W(e, ln_prefix + "bias"), (size_t)dim, s, b);
+    if (rc) return rc;
+    const float hi = sqrtf((float)dim) * g + b, lo = fmaxf(g, b);
+    if (e->range_static.empty() && (!(hi < kRangeHi) || lo < kRangeLo)) {
+        char msg[320];
+        snprintf(msg, sizeof msg, "activation range: the output of '%s*' (max|weight| = %.6g, max|bias| = %.6g) is %s the range precision mode "
+                 "f16x3 represents to fp32 class (%g <= max|x| < %g)", ln_prefix.c_str(), (double)g, (double)b,
+                 !(hi < kRangeHi) ? "not bounded inside" : "below", (double)kRangeLo, (double)kRangeHi);
+        e->range_static = msg;
+    }
     return LOCO_OK;
 }
 
@@ -480,6 +549,20 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         hi = reinterpret_cast<_Float16*>(base);
         lo = hi + n;
     };
+    // range tracking: one status word (x 8 shards) per tensor that is stored as fp16 planes and whose range does not follow from
+    // the weights alone (loco_kernels.h), in launch order; the two halves of a dual-stream forward walk the same sequence and
+    // share the words (a maximum does not care who contributes)
+    int nslot = 0;
+    auto slot = [&](const char* name, int layer = -1) -> float* {
+        if (!e->range_dev || nslot >= kRangeMaxStages) return nullptr;
+        e->range_names[nslot] = name;
+        e->range_layer[nslot] = layer;
+        return e->range_dev + (size_t)kRangeShards * nslot++;
+    };
+    static const char* const kConvNames[7] = {"feature_encoder.conv_layers.0 (GroupNorm + GELU)", "feature_encoder.conv_layers.1",
+                                              "feature_encoder.conv_layers.2", "feature_encoder.conv_layers.3",
+                                              "feature_encoder.conv_layers.4", "feature_encoder.conv_layers.5",
+                                              "feature_encoder.conv_layers.6"};
 
     if (!skip_prenet) {
     // ---- feature encoder: conv0 writes planes, conv1-5 planes -> planes, conv6 planes -> fp32 (LayerNorm input)
@@ -501,7 +584,8 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         const bool last = i == 6;
         rc = run_gemm_split(e, s, ihi, ilo, (long)kConvS[i] * kConvDim, e->conv_s[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
                             last ? cout : nullptr, last ? nullptr : ohi, last ? nullptr : olo, kConvDim, (int)Tout, kConvDim,
-                            kConvK[i] * kConvDim, kEpiGelu, B, Tin * kConvDim, Tout * kConvDim);
+                            kConvK[i] * kConvDim, kEpiGelu, B, Tin * kConvDim, Tout * kConvDim, 1, 0, 0, nullptr, nullptr, nullptr,
+                            last ? nullptr : slot(kConvNames[i]));
         if (rc) return rc;
         float* t = cin;
         cin = cout;
@@ -528,7 +612,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         _Float16* glo = ghi + (size_t)B * kPosGroups * (T + kPosK) * kPosCg;
         {
             Bracket br(e, s, K_COPY, 0.0, 8.0 * M * kHidden);
-            HIP_TRY(launch_group_major_split(x1, ghi, glo, B, T, s));
+            HIP_TRY(launch_group_major_split(x1, ghi, glo, B, T, s, slot("feature_projection (input of pos_conv_embed)")));
         }
         GemmSplitArgs a{};
         a.Ahi = ghi; a.Alo = glo; a.Whi = e->posg_s.hi; a.Wlo = e->posg_s.lo;
@@ -541,8 +625,10 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         a.sC1 = (long)T * kHidden; a.sC2 = kPosCg;
         a.sW2 = (long)kPosCg * kPosK * kPosCg; a.sBias2 = kPosCg;
         a.epilogue = kEpiPosConv;
+        a.out_scale = e->posg_s.inv_scale;
+        a.terms = e->precision == 2 ? 2 : 3;
         a.sin_table = e->sin_tab; a.frames = frames_or_null; a.T = T;
-        Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
+        Bracket br(e, s, K_POSCONV_SPLIT, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
         HIP_TRY(launch_gemm_split(a, s));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
@@ -566,15 +652,17 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         const LayerW& lw = e->layers[l];
         // fused q|k|v projection -> q, k as fp16 hi/lo planes, v transposed per head (the layouts attention_f16x3 reads)
         if ((rc = run_gemm_split(e, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, nullptr, qshi, qslo, kHidden, (int)M,
-                                 kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat)))
+                                 kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat, nullptr, nullptr,
+                                 slot("attention q|k|v projections", l))))
             return rc;
         // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320]
         if ((rc = run_gemm_split(e, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
-                                 kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN)))
+                                 kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN,
+                                 nullptr, nullptr, nullptr, nullptr, K_QP)))
             return rc;
         {
             const double tt = (double)T * T;
-            Bracket br(e, s, K_ATTN, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
+            Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
             HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
                                            Tp, s));
         }
@@ -583,7 +671,8 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
             return rc;
         if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), nullptr, M, kHidden, x1hi, x1lo))) return rc;
         if ((rc = run_gemm_split(e, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
-                                 nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu)))
+                                 nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu, 1, 0, 0, 1, 0, 0, nullptr, nullptr,
+                                 nullptr, slot("feed_forward intermediate (GELU)", l))))
             return rc;
         if ((rc = run_gemm_split(e, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), nullptr, kHidden,
                                  tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x1hi,
@@ -596,6 +685,20 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     }
     if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
     if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
+    e->range_used = nslot;
+    return LOCO_OK;
+}
+
+// The status words travel to pinned host memory behind the forward, on its stream: readable once the stream has got there.
+int range_begin(loco_encoder* e, hipStream_t s) {
+    e->range_used = 0;
+    e->range_forward.clear();
+    if (e->range_dev) HIP_TRY(hipMemsetAsync(e->range_dev, 0, sizeof(float) * kRangeMaxStages * kRangeShards, s));
+    return LOCO_OK;
+}
+int range_end(loco_encoder* e, hipStream_t s) {
+    if (e->range_dev && e->range_used > 0)
+        HIP_TRY(hipMemcpyAsync(e->range_host, e->range_dev, sizeof(float) * kRangeShards * e->range_used, hipMemcpyDeviceToHost, s));
     return LOCO_OK;
 }
 
@@ -645,6 +748,16 @@ loco_encoder* loco_create(const loco_config* cfg) {
     loco_encoder* e = new loco_encoder();
     e->cfg = c;
     e->device = dev;
+    if (hipMalloc(&e->range_dev, sizeof(float) * kRangeMaxStages * kRangeShards) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&e->range_host), sizeof(float) * kRangeMaxStages * kRangeShards, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&e->absmax_dev, sizeof(float)) != hipSuccess) {
+        fail(LOCO_E_HIP, "loco_create: could not allocate the range-status words");
+        (void)hipFree(e->range_dev);
+        if (e->range_host) (void)hipHostFree(e->range_host);
+        delete e;
+        return nullptr;
+    }
+    memset(e->range_host, 0, sizeof(float) * kRangeMaxStages * kRangeShards);
     e->layers.resize(c.layers);
     build_expected(e);
     for (int i = 0; i < K_COUNT; ++i) {
@@ -675,6 +788,9 @@ void loco_destroy(loco_encoder* e) {
         free_split(l.s1);
         free_split(l.s2);
     }
+    (void)hipFree(e->range_dev);
+    (void)hipFree(e->absmax_dev);
+    if (e->range_host) (void)hipHostFree(e->range_host);
     (void)hipFree(e->sin_tab);
     (void)hipFree(e->text_embed);
     (void)hipFree(e->text_alpha);
@@ -820,15 +936,15 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     // fp16 hi/lo planes of every GEMM weight for precision mode f16x3 (378 MB; built unconditionally so that the
     // mode can be switched per forward)
     int rc = LOCO_OK;
-    for (int i = 1; speech && i < 7 && !rc; ++i) rc = make_split(e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
-    if (speech && !rc) rc = make_split(e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
-    if (!rc) rc = make_split(e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
+    for (int i = 1; speech && i < 7 && !rc; ++i) rc = make_split(e, e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
+    if (speech && !rc) rc = make_split(e, e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
+    if (!rc) rc = make_split(e, e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
     if (speech && !rc) {  // positional conv weight re-laid [g][o][tap*48+i] for the conv-as-GEMM form, then split
         float* tmpw = nullptr;
         const size_t n = (size_t)kHidden * kPosCg * kPosK;
         HIP_TRY(hipMalloc(&tmpw, n * sizeof(float)));
         hipError_t he = launch_pos_w_for_gemm(e->pos_w, tmpw, s);
-        if (he == hipSuccess) rc = make_split(e->posg_s, tmpw, n, s);
+        if (he == hipSuccess) rc = make_split(e, e->posg_s, tmpw, n, s);
         HIP_TRY(hipStreamSynchronize(s));
         (void)hipFree(tmpw);
         if (he != hipSuccess) return fail(LOCO_E_HIP, "pos_w_for_gemm: %s", hipGetErrorString(he));
@@ -836,16 +952,31 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     for (int l = 0; l < e->cfg.layers && !rc; ++l) {
         LayerW& lw = e->layers[l];
         const std::string b = w + "layers." + std::to_string(l) + ".";
-        rc = make_split(lw.sqkv, lw.wqkv, 3 * hh, s);
-        if (!rc) rc = make_split(lw.so, W(e, b + "attention.out_proj.weight"), hh, s);
-        if (!rc) rc = make_split(lw.s1, W(e, b + "feed_forward.intermediate_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
-        if (!rc) rc = make_split(lw.s2, W(e, b + "feed_forward.output_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
+        rc = make_split(e, lw.sqkv, lw.wqkv, 3 * hh, s);
+        if (!rc) rc = make_split(e, lw.so, W(e, b + "attention.out_proj.weight"), hh, s);
+        if (!rc) rc = make_split(e, lw.s1, W(e, b + "feed_forward.intermediate_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
+        if (!rc) rc = make_split(e, lw.s2, W(e, b + "feed_forward.output_dense.weight"), (size_t)e->cfg.ffn * kHidden, s);
     }
     if (rc) return rc;
     if (speech) {
         rc = ensure_sin_rows(e, 4002, s);
         if (rc) return rc;
     }
+    // weight-determined activation ranges of precision mode f16x3 (static_range_check above)
+    e->range_static.clear();
+    e->gn_gmax = e->gn_bmax = 0.f;
+    if (speech) {
+        rc = absmax_host(e, W(e, p + "feature_encoder.conv_layers.0.layer_norm.weight"), kConvDim, s, e->gn_gmax);
+        if (!rc) rc = absmax_host(e, W(e, p + "feature_encoder.conv_layers.0.layer_norm.bias"), kConvDim, s, e->gn_bmax);
+        if (!rc) rc = static_range_check(e, p + "feature_projection.layer_norm.", kConvDim, s);
+    }
+    if (!rc) rc = static_range_check(e, w + "layer_norm.", kHidden, s);
+    for (int l = 0; l < e->cfg.layers && !rc; ++l) {
+        const std::string b = w + "layers." + std::to_string(l) + ".";
+        rc = static_range_check(e, b + "layer_norm.", kHidden, s);
+        if (!rc && l + 1 < e->cfg.layers) rc = static_range_check(e, b + "final_layer_norm.", kHidden, s);  // the last one is written in fp32
+    }
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     e->speech_ready = speech;
     e->finalized = true;
@@ -887,7 +1018,7 @@ int loco_set_streams(loco_encoder* e, int n) {
 }
 
 int loco_set_precision(loco_encoder* e, int mode) {
-    if (!e || (mode != 0 && mode != 1)) return fail(LOCO_E_INVALID, "loco_set_precision: mode must be 0 (f32) or 1 (f16x3)");
+    if (!e || mode < 0 || mode > 2) return fail(LOCO_E_INVALID, "loco_set_precision: mode must be 0 (f32), 1 (f16x3) or 2 (f16x2)");
     e->precision = mode;
     return LOCO_OK;
 }
@@ -926,7 +1057,7 @@ int forward_one(loco_encoder* e, const Plan& p, const float* wav, const int32_t*
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
     e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
-    return e->precision == 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
+    return e->precision >= 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
 }
 }  // namespace
 
@@ -951,7 +1082,23 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     int rc = ensure_sin_rows(e, (int)p.T + 2, s);
     if (rc) return rc;
     char* ws = reinterpret_cast<char*>(workspace);
-    if (!dual) return forward_one(e, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
+    if ((rc = range_begin(e, s))) return rc;
+    if (e->precision >= 1) {  // conv0's GroupNorm + GELU output: bounded by sqrt(frames) max|gamma| + max|beta| (static_range_check)
+        const float hi = sqrtf((float)p.Tc[0]) * e->gn_gmax + e->gn_bmax, lo = fmaxf(e->gn_gmax, e->gn_bmax);
+        if (!(hi < kRangeHi) || lo < kRangeLo) {
+            char msg[320];
+            snprintf(msg, sizeof msg, "activation range: the output of 'prenet.feature_encoder.conv_layers.0' (GroupNorm max|weight| = %.6g, "
+                     "max|bias| = %.6g, %ld frames per clip) is %s the range precision mode f16x3 represents to fp32 class (%g <= max|x| < %g)",
+                     (double)e->gn_gmax, (double)e->gn_bmax, p.Tc[0], !(hi < kRangeHi) ? "not bounded inside" : "below", (double)kRangeLo,
+                     (double)kRangeHi);
+            e->range_forward = msg;
+        }
+    }
+    if (!dual) {
+        rc = forward_one(e, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
+        if (rc) return rc;
+        return range_end(e, s);
+    }
 
     if (!e->side) {
         HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -961,12 +1108,94 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     const int B0 = (B + 1) / 2, B1 = B - B0;
     HIP_TRY(hipEventRecord(e->ev_fork, s));  // the side stream starts after everything already queued on the caller's stream
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+    // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
+    // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
     rc = forward_one(e, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
-    const int rc1 = forward_one(e, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
-                                out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
-    HIP_TRY(hipEventRecord(e->ev_join, e->side));  // ... and the caller's stream continues after both halves
-    HIP_TRY(hipStreamWaitEvent(s, e->ev_join, 0));
-    return rc ? rc : rc1;
+    int rc1 = LOCO_OK;
+    std::string first_error;
+    if (rc) first_error = g_err;
+    else rc1 = forward_one(e, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
+                           out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
+    if (!rc && rc1) first_error = g_err;
+    const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves
+    const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, e->ev_join, 0) : j1;
+    if (j2 != hipSuccess) {
+        // the join itself failed: block until the side stream has drained rather than hand back a workspace in use
+        (void)hipStreamSynchronize(e->side);
+        if (!rc && !rc1) return fail(LOCO_E_HIP, "loco_forward: joining the second stream failed: %s", hipGetErrorString(j2));
+    }
+    if (rc || rc1) {
+        g_err = first_error;
+        return rc ? rc : rc1;
+    }
+    return range_end(e, s);
+}
+
+// ---- range status of the last forward (include/loco_asr.h) -----------------------------------------------------------------
+int loco_forward_status(loco_encoder* e, char* buf, size_t buflen) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    if (buf && buflen) buf[0] = 0;
+    if (e->precision >= 1) {
+        const std::string& m = !e->range_static.empty() ? e->range_static : e->range_forward;
+        if (!m.empty()) {
+            if (buf && buflen) snprintf(buf, buflen, "%s", m.c_str());
+            return fail(LOCO_E_RANGE, "%s; use the exact-fp32 kernels for this model (loco_set_precision(enc, 0) / loco_forward_checked)", m.c_str());
+        }
+    }
+    for (int i = 0; i < e->range_used; ++i) {
+        float amax = 0.f;
+        for (int k = 0; k < kRangeShards; ++k) amax = fmaxf(amax, e->range_host[(size_t)i * kRangeShards + k]);
+        const bool over = !(amax < kRangeHi), under = amax < kRangeLo;
+        if (!over && !under) continue;
+        char where[160];
+        if (e->range_layer[i] >= 0) snprintf(where, sizeof where, "wrapped_encoder.layers.%d %s", e->range_layer[i], e->range_names[i]);
+        else snprintf(where, sizeof where, "%s", e->range_names[i]);
+        char msg[400];
+        snprintf(msg, sizeof msg,
+                 "activation range: max|x| = %.6g of '%s' is %s the range precision mode f16x3 represents to fp32 class "
+                 "(%g <= max|x| < %g); use the exact-fp32 kernels for this input (loco_set_precision(enc, 0) / loco_forward_checked)",
+                 (double)amax, where, over ? "above" : "below", (double)kRangeLo, (double)kRangeHi);
+        if (buf && buflen) snprintf(buf, buflen, "%s", msg);
+        return fail(LOCO_E_RANGE, "%s", msg);
+    }
+    return LOCO_OK;
+}
+
+int loco_forward_range(const loco_encoder* e, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    if (stage < 0 || stage >= e->range_used) return e->range_used;  // not an error: lets a caller enumerate 0 .. n-1
+    float m = 0.f;
+    for (int k = 0; k < kRangeShards; ++k) m = fmaxf(m, e->range_host[(size_t)stage * kRangeShards + k]);
+    if (amax) *amax = m;
+    if (layer) *layer = e->range_layer[stage];
+    if (name && namelen) snprintf(name, namelen, "%s", e->range_names[stage]);
+    return e->range_used;
+}
+
+int loco_set_range_policy(loco_encoder* e, int policy) {
+    if (!e || (policy != 0 && policy != 1)) return fail(LOCO_E_INVALID, "loco_set_range_policy: policy must be 0 (report) or 1 (re-run in fp32)");
+    e->range_policy = policy;
+    return LOCO_OK;
+}
+
+int loco_forward_checked(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out, int32_t* out_frames,
+                         float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream, int32_t* used_fp32) {
+    if (used_fp32) *used_fp32 = 0;
+    int rc = loco_forward(e, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (e->precision == 0) return LOCO_OK;  // the exact-fp32 mode stores no fp16 planes
+    rc = loco_forward_status(e, nullptr, 0);
+    if (rc != LOCO_E_RANGE || e->range_policy == 0) return rc;
+    // out of the fp16 planes' range: the same batch again on the exact-fp32 MFMA kernels of this library
+    const int mode = e->precision;
+    e->precision = 0;
+    rc = loco_forward(e, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
+    e->precision = mode;
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    if (used_fp32) *used_fp32 = 1;
+    return LOCO_OK;
 }
 
 // ---- text front end ---------------------------------------------------------------------------------------
@@ -997,6 +1226,8 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
     char* ws = reinterpret_cast<char*>(workspace);
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* x0 = reinterpret_cast<float*>(ws + p.off_x0);
+    int rcb = range_begin(e, s);
+    if (rcb) return rcb;
     {
         Bracket br(e, s, K_FRAMES, 0.0, attention_mask ? 4.0 * B * (double)T : 0.0);
         HIP_TRY(launch_token_counts(attention_mask, B, T, frames, s));
@@ -1011,8 +1242,9 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
                      reinterpret_cast<float*>(ws + p.off_qp), reinterpret_cast<float*>(ws + p.off_ffn),
                      reinterpret_cast<_Float16*>(ws + p.off_xs0), reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
     e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
-    return e->precision == 1 ? forward_f16x3(e, p, nullptr, out, hidden_states, bufs, s, true)
-                             : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
+    const int rc = e->precision >= 1 ? forward_f16x3(e, p, nullptr, out, hidden_states, bufs, s, true)
+                                     : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
+    return rc ? rc : range_end(e, s);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------
@@ -1113,6 +1345,31 @@ int loco_op_normalize_waveform(const float* wav, const int32_t* attention_mask, 
         return fail(LOCO_E_WORKSPACE, "loco_op_normalize_waveform: scratch %zu < %zu bytes (or not 8-byte aligned)", scratch_bytes,
                     normalize_scratch_bytes(B));
     HIP_TRY(launch_normalize_waveform(wav, attention_mask, B, L, padding_value, out, scratch, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+// ---- sample-rate conversion ("next" row f-4) -----------------------------------------------------------------------------
+int loco_resample_design(int32_t sr_in, int32_t sr_out, int32_t* up, int32_t* down, int32_t* taps_per_phase, float* taps_host) {
+    if (!up || !down || !taps_per_phase) return fail(LOCO_E_INVALID, "loco_resample_design: null argument");
+    int L = 0, M = 0, K = 0;
+    const int rc = resample_design(sr_in, sr_out, &L, &M, &K, taps_host);
+    if (rc) return fail(LOCO_E_INVALID, "loco_resample_design: unsupported rates %d -> %d Hz", sr_in, sr_out);
+    *up = L; *down = M; *taps_per_phase = K;
+    return LOCO_OK;
+}
+
+int64_t loco_resample_length(int64_t n_in, int32_t up, int32_t down) {
+    if (n_in <= 0 || up <= 0 || down <= 0) return 0;
+    return (n_in * up + down - 1) / down;  // ceil(n * sr_out / sr_in): librosa.resample's n_samples (+ fix_length)
+}
+
+int loco_op_resample(const float* x, int32_t B, int64_t n_in, int64_t x_stride, const float* taps_dev, int32_t up, int32_t down,
+                     int32_t taps_per_phase, float* y, int64_t n_out, int64_t y_stride, void* stream) {
+    if (!x || !taps_dev || !y) return fail(LOCO_E_INVALID, "loco_op_resample: null argument");
+    if (B <= 0 || n_in <= 0 || n_out <= 0 || n_out > loco_resample_length(n_in, up, down) || x_stride < n_in || y_stride < n_out ||
+        (reinterpret_cast<uintptr_t>(taps_dev) & 15))
+        return fail(LOCO_E_INVALID, "loco_op_resample: invalid shape (n_out must be <= ceil(n_in * up / down); taps 16-byte aligned)");
+    HIP_TRY(launch_resample(x, B, n_in, x_stride, taps_dev, up, down, taps_per_phase, y, n_out, y_stride, (hipStream_t)stream));
     return LOCO_OK;
 }
 

@@ -72,6 +72,14 @@ struct GemmSplitArgs {
     int T = 0, Tp = 0;
     // kEpiPosConv (grouped positional conv as a GEMM over the group-major halo layout, see launch_group_major_split):
     // z1 = clip, z2 = group; C = R + GELU(acc + bias) + sin_table[pos(t)], pos = t+2 for t < frames[z1] else 1
+    // The weight planes hold W * 2^k (k chosen per tensor at load time so that max|W| lands in [2^13, 2^14): fp16's 5-bit
+    // exponent then serves the weights' own spread instead of their absolute level); the accumulator is multiplied by
+    // out_scale = 2^-k before bias / activation -- exact, a power of two.
+    float out_scale = 1.0f;
+    int terms = 3;  // 3: A_hi W_hi + A_lo W_hi + A_hi W_lo;  2: the W_lo term dropped (precision mode "f16x2")
+    // Range tracking: where the output is written as fp16 hi/lo planes, max|x| of what was written is folded into
+    // range_slot[0..7] (see range_commit); null = not tracked.
+    float* range_slot = nullptr;
     long sW2 = 0;                   // weight stride per z2 (0 = shared weights)
     long sBias2 = 0;                // bias stride per z2
     const float* sin_table = nullptr;
@@ -79,14 +87,61 @@ struct GemmSplitArgs {
 };
 // x [B,T,768] fp32 -> fp16 hi/lo planes in group-major layout [B][16][T+128][48] with 64 zero frames before and after:
 // output frame t of group g then reads the CONTIGUOUS run rows t .. t+127 (128 taps x 48 channels = K 6144, lda = 48)
-hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s);
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot = nullptr);
 // folded positional-conv weight [g][tap][o][i] -> [g][o][tap*48 + i] (the GEMM's W, ldw = 6144)
 hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s);
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
                                   _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s);
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
-hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s);
+// hi/lo planes of x * scale (scale a power of two)
+hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s, float scale = 1.0f);
+// max |x| over n elements -> *out (one float, device); out must be zeroed by the caller
+hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s);
+
+// ---- range tracking of tensors stored as fp16 hi/lo planes (precision mode f16x3) ------------------------------------------
+// hi = fp16(x) is inf from |x| >= 65520 on, and the pair (hi, lo) keeps 22 significant bits only while lo = fp16(x - hi) is a
+// normal fp16 number, i.e. for |x| >~ 2^-3; below that the ABSOLUTE error levels off at 2^-25.  A tensor is therefore
+// represented to fp32 class relative to its own scale as long as its largest element sits well inside (2^-6, 65504) -- the
+// range include/loco_asr.h guarantees.
+//   * Tensors whose range follows from the weights alone are checked on the host, at no run-time cost: LayerNorm outputs
+//     (|y| <= sqrt(D) max|gamma| + max|beta|), conv0's GroupNorm + GELU output (the same with D = frames per clip), the
+//     attention context (a convex combination of V rows) -- loco_api.hip, static_range_check.
+//   * The unbounded ones -- GELU outputs of conv layers 1-5 and of the feed-forward intermediate, q|k|v, the feature
+//     projection -- are tracked where they are produced: the GEMM epilogue (and group_major_split) folds max|x| of what it
+//     writes, taken on the fp32 value before conversion, into its stage's status word.  8 shards per stage (workgroup id mod
+//     8) so that no single address takes every workgroup's atomic; the word is read EARLY (range_peek, before the epilogue's
+//     arithmetic, so the load's latency is hidden) and a wave whose maximum is already covered skips the atomic -- the word
+//     only grows, so a stale read costs at most a redundant atomic.  The wave maximum is taken with four DPP steps inside
+//     the rows of 16 lanes and four v_readlane across them: no LDS traffic, no waits.
+// The host reads the words after the forward (loco_forward_status) and decides (include/loco_asr.h).
+constexpr int kRangeShards = 8;
+constexpr int kRangeMaxStages = 96;
+__device__ __forceinline__ unsigned range_peek(const float* slot) {
+    if (!slot) return 0xffffffffu;
+    return __hip_atomic_load(reinterpret_cast<const unsigned*>(slot) + (blockIdx.x & (kRangeShards - 1)), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+// max over the wave's 64 lanes of a NON-NEGATIVE value (lanes without a partner read 0); every lane must be active
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+#define LOCO_DPP_MAX(ctrl) \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, true)))
+    LOCO_DPP_MAX(0xB1);   // quad_perm [1,0,3,2]: lane ^ 1
+    LOCO_DPP_MAX(0x4E);   // quad_perm [2,3,0,1]: lane ^ 2
+    LOCO_DPP_MAX(0x141);  // row_half_mirror: the other quad of each 8
+    LOCO_DPP_MAX(0x140);  // row_mirror: the other half of each row of 16
+#undef LOCO_DPP_MAX
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+__device__ __forceinline__ void range_commit(float* slot, float amax, unsigned seen) {
+    if (!slot) return;
+    const unsigned bits = __float_as_uint(wave_max_nonneg(amax));  // non-negative floats order like their bit patterns; NaN never enters (fmaxf)
+    if ((threadIdx.x & 63) == 0 && bits > seen)
+        atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x & (kRangeShards - 1)), bits);
+}
 
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
 // Column of frame t in a V^T plane row: bits 2 and 3 of t are swapped, i.e. each aligned group of 16 frames is stored as
@@ -198,6 +253,11 @@ hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C,
 hipError_t launch_fold_pos_conv(const float* g, const float* v, float* out, hipStream_t s);  // -> [16][128][48][48]
 hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
 hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s);
+
+// sample-rate conversion (resample.hip)
+int resample_design(int sr_in, int sr_out, int* L_out, int* M_out, int* K_out, float* taps);
+hipError_t launch_resample(const float* x, int B, long n_in, long x_stride, const float* taps, int L, int M, int K, float* y, long n_out,
+                           long y_stride, hipStream_t s);
 
 inline long conv_out_len(long n, int k, int s) { return n < k ? 0 : (n - k) / s + 1; }
 

@@ -373,4 +373,20 @@ hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s) {
     return hipGetLastError();
 }
 
+// max |x| (used once per weight tensor at load time to choose its power-of-two plane scale)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
+
+hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s) {
+    if (n <= 0 || !x || !out) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, x, n, out);
+    return hipGetLastError();
+}
+
 }  // namespace loco

@@ -10,9 +10,18 @@ only collective is the gather of the finished embeddings:
     payload  : all_gather_into_tensor of f32 [B_loc, T_max, 768]         -- 147 MB/rank at 30 s x 32
 
 On ROCm the "nccl" backend is RCCL; over the xGMI full mesh an all-gather of this size is a few ms
-against >100 ms of compute per step.  Units are dealt to ranks in contiguous blocks after sorting by
-length, longest first (attention cost grows with T^2, so equal counts of similar lengths balance best
-and padding inside a rank's batch is minimal).
+against >100 ms of compute per step.
+
+Two ways of dealing units to ranks:
+
+* ``shard_batches`` (the default of the CLI and of ``encode_sharded``): the corpus is cut into consecutive batches in
+  corpus order -- exactly the batches ``DataLoader(dataset, batch_size=b, shuffle=False)`` forms in the reference
+  (…base…py:67-68) -- and WHOLE batches are dealt round-robin (rank r encodes batches r, r+W, r+2W, ...).  Batch
+  composition is part of the function (GroupNorm statistics run over the padded axis), so this is what keeps the
+  per-utterance output identical to the reference's at any world size.
+* ``shard_units`` (opt-in, ``--bucket-by-length``): single units sorted by length, longest first, dealt round-robin
+  (rank r gets sorted positions r, r+W, ...): attention cost grows with T^2, so equal counts of similar lengths
+  balance best and padding inside a batch is minimal -- but the batches differ from the reference's.
 
 Everything here works with any torch.distributed backend: tests run it on CPU with gloo, world size 2.
 """
@@ -25,10 +34,27 @@ import torch.distributed as dist
 
 
 def shard_units(lengths: Sequence[int], world_size: int, rank: int) -> List[int]:
-    """Indices of the units this rank encodes.  Longest-first order dealt round-robin in blocks:
+    """Indices of the units this rank encodes, bucketed by length: longest-first order dealt round-robin,
     rank r gets sorted positions r, r+W, r+2W, ...  -> equal counts (+-1) and matched lengths."""
     order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
     return order[rank::world_size]
+
+
+def corpus_batches(n_units: int, batch_size: int) -> List[List[int]]:
+    """The batches DataLoader(batch_size=b, shuffle=False) forms: consecutive runs of the corpus order, last one short."""
+    return [list(range(a, min(n_units, a + batch_size))) for a in range(0, n_units, batch_size)]
+
+
+def shard_batches(n_units: int, batch_size: int, world_size: int, rank: int) -> List[List[int]]:
+    """This rank's share of ``corpus_batches``: whole batches dealt round-robin, so every batch any rank encodes is one the
+    single-process reference loop encodes."""
+    return corpus_batches(n_units, batch_size)[rank::world_size]
+
+
+def rounds(n_units: int, batch_size: int, world_size: int) -> int:
+    """Steps every rank takes (ranks that have run out contribute empty batches so that collectives line up)."""
+    nb = (n_units + batch_size - 1) // batch_size
+    return (nb + world_size - 1) // world_size
 
 
 def window_units(lengths: Sequence[int], window: int, min_samples: int = 400) -> List[Tuple[int, int, int]]:
@@ -133,16 +159,22 @@ def gather_ragged(local: torch.Tensor, local_ids: Sequence[int], n_total: int, g
     return res
 
 
-def encode_sharded(encode_fn: Callable, clips: Sequence, make_batch: Callable, device, group=None, max_batch: int = 32):
+def encode_sharded(encode_fn: Callable, clips: Sequence, make_batch: Callable, device, group=None, max_batch: int = 2,
+                   bucket_by_length: bool = False):
     """Encode `clips` (list of 1-D waveforms) data-parallel and return the per-clip embeddings on every rank.
 
     encode_fn(input_values, attention_mask) -> [B, T, 768] tensor (the MI355X encoder's forward);
-    make_batch(list_of_clips) -> (input_values, attention_mask) on the encoder's device `device`."""
+    make_batch(list_of_clips) -> (input_values, attention_mask) on the encoder's device `device`.
+    Batches are the reference's (corpus order, `max_batch` = its batch_size = 2) unless bucket_by_length is set."""
     world, rank = _world(group)
     lengths = [len(c) for c in clips]
-    mine = shard_units(lengths, world, rank)
-    chunks = [mine[i:i + max_batch] for i in range(0, len(mine), max_batch)]
-    n_rounds = (max(len(shard_units(lengths, world, r)) for r in range(world)) + max_batch - 1) // max_batch
+    if bucket_by_length:
+        mine = shard_units(lengths, world, rank)
+        chunks = [mine[i:i + max_batch] for i in range(0, len(mine), max_batch)]
+        n_rounds = (max(len(shard_units(lengths, world, r)) for r in range(world)) + max_batch - 1) // max_batch
+    else:
+        chunks = shard_batches(len(clips), max_batch, world, rank)
+        n_rounds = rounds(len(clips), max_batch, world)
     results = [None] * len(clips)
     for k in range(n_rounds):
         ids = chunks[k] if k < len(chunks) else []

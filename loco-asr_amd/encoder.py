@@ -165,9 +165,12 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
     """Drop-in for ``SpeechT5ForSpeechToText(...).speecht5.encoder`` (HF modeling_speecht5.py:1325-1358)."""
 
     # "f16x3" (default): GEMMs and attention products as three fp16 MFMAs per fp32-class product (hi/lo operand split,
-    # fp32 accumulate) -- 3.5e-6 relative L2 of an fp64 evaluation end to end, 2x the speed of "f32";
-    # "f32": every contraction on the exact fp32 MFMA (2.3e-6).  Both are far inside the 1e-3 bar.
-    PRECISIONS = {"f32": 0, "f16x3": 1}
+    # fp32 accumulate) -- ~1e-6 relative L2 of an fp64 evaluation end to end, 2.4x the speed of "f32";
+    # "f32": every contraction on the exact fp32 MFMA (~1e-6).  Both are far inside the 1e-3 bar.
+    # "f16x2" (opt-in, never the default): the weights of every projection / conv GEMM rounded to fp16 (after their
+    # per-tensor power-of-two scale), activations still hi + lo, attention products still three-term -- ~4e-4, inside the
+    # 1e-3 bar but no longer fp32 class; a third fewer matrix instructions in the GEMMs.
+    PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2}
 
     def __init__(self, layers: int = LAYERS, precision: str = "f16x3"):
         super().__init__()
@@ -193,6 +196,12 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         # large batches run as two half-batches on two HIP streams (bit-identical, ~2 % faster: include/loco_asr.h,
         # loco_set_streams); set to 1 to keep everything on the caller's stream
         self.streams = 2
+        # Numeric range of precision "f16x3" (include/loco_asr.h): "fp32" = a batch whose activations leave the range the fp16
+        # planes represent is run again on the library's exact-fp32 MFMA kernels (the default: a caller never sees NaNs or a
+        # silently degraded embedding); "raise" = LocoError instead; "off" = no check and no host synchronisation (the
+        # forward stays fully asynchronous; loco_forward_status can still be queried through range_report()).
+        self.range_policy = "fp32"
+        self.last_range_fallback = False
         self.eval()
 
     # -- lifetime ----------------------------------------------------------------------------------------
@@ -244,10 +253,13 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             rows = max(MAX_SPEECH_POSITIONS + PAD_TOKEN_ID + 1 + 2, min_sin_rows + 2)
             tab = sinusoid_table(rows).contiguous()
             shape = (C.c_int64 * 2)(rows, HIDDEN)
+            # captured hipGraphs hold the device pointer of the table this call replaces (the library frees the old one)
+            self._graphs.clear()
             _lib.check(self._lib.loco_set_weight(self._handle, b"prenet.pos_sinusoidal_embed.weights",
                                                  C.c_void_p(tab.data_ptr()), shape, 2), "sinusoid table")
             self._sin_rows = rows
         if self._weights_dirty:
+            self._graphs.clear()  # re-finalised weights live at new addresses
             _lib.check(self._lib.loco_finalize_weights(self._handle, stream), "finalize_weights")
             self._weights_dirty = False
 
@@ -264,6 +276,29 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         n = _lib.check(self._lib.loco_profile_read(self._handle, arr, 16))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches, ms=arr[i].ms, flops=arr[i].flops,
                      bytes=arr[i].bytes) for i in range(n)]
+
+    def range_report(self):
+        """max|x| of every tensor the last f16x3 forward stored as fp16 planes: [(name, layer or -1, amax)] -- call after the
+        forward has completed (the numbers follow it to host memory on its stream)."""
+        out, i = [], 0
+        amax, layer, name = C.c_float(), C.c_int32(), C.create_string_buffer(160)
+        while i < self._lib.loco_forward_range(self._handle, i, C.byref(amax), C.byref(layer), name, 160):
+            out.append((name.value.decode(), int(layer.value), float(amax.value)))
+            i += 1
+        return out
+
+    def _forward_call(self, args, stream):
+        """loco_forward under the module's range policy (include/loco_asr.h, 'numeric range of precision mode f16x3')."""
+        self.last_range_fallback = False
+        if self.range_policy == "off":
+            _lib.check(self._lib.loco_forward(self._handle, *args, stream), "loco_forward")
+            return
+        if self.range_policy not in ("fp32", "raise"):
+            raise ValueError("range_policy must be 'fp32', 'raise' or 'off'")
+        _lib.check(self._lib.loco_set_range_policy(self._handle, 1 if self.range_policy == "fp32" else 0), "set_range_policy")
+        used = C.c_int32(0)
+        _lib.check(self._lib.loco_forward_checked(self._handle, *args, stream, C.byref(used)), "loco_forward")
+        self.last_range_fallback = bool(used.value)
 
     def workspace_bytes(self, batch: int, samples: int) -> int:
         self._ensure_handle(self._device())
@@ -325,11 +360,9 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
                                                    taps["feature_projection"].data_ptr(), taps["prenet"].data_ptr()))
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
             try:
-                _lib.check(self._lib.loco_forward(self._handle, C.c_void_p(x.data_ptr()),
-                                                  C.c_void_p(m.data_ptr()) if m is not None else None, B, L,
-                                                  C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
-                                                  C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream),
-                           "loco_forward")
+                self._forward_call((C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None, B, L,
+                                    C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
+                                    C.c_void_p(self._workspace.data_ptr()), self._workspace.numel()), stream)
             finally:
                 if taps is not None:
                     _lib.check(self._lib.loco_set_taps(self._handle, None, None, None))
@@ -381,6 +414,18 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             if ms is not None:
                 ms.copy_(m)
             g.replay()
+            self.last_range_fallback = False
+            if self.range_policy != "off":  # the captured forward carries its status copy: read it once the replay is done
+                torch.cuda.current_stream(device).synchronize()
+                if self._lib.loco_forward_status(self._handle, None, 0) != 0:
+                    if self.range_policy == "raise":
+                        _lib.check(-5, "loco_forward (hipGraph replay)")
+                    out, frames = torch.empty_like(outs), torch.empty_like(frs)
+                    self._forward_call((C.c_void_p(xs.data_ptr()), C.c_void_p(ms.data_ptr()) if ms is not None else None, B, L,
+                                        C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None,
+                                        C.c_void_p(self._workspace.data_ptr()), self._workspace.numel()),
+                                       C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+                    return out, frames
             return outs.clone(), frs.clone()
 
 

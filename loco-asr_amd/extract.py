@@ -7,14 +7,21 @@ extract_speecht5_finetuned_embeddings_slurp.py:93-113) on MI355X.
     python loco-asr_amd/extract.py -m audio -s devel --synthetic 64        # no corpus: seeded synthetic clips
     torchrun --standalone --nproc-per-node 8 loco-asr_amd/extract.py -m audio -s train     # data parallel
 
-Same flags (-m/--modality, -s/--split), same folder layout (extracted/<model>/<split>/<modality>/) and the same
-per-utterance pickle as the reference; the encoder is the HIP implementation behind the C ABI.  What differs,
-by necessity: weights come from ``--prenet-state-dict`` / ``--encoder-state-dict`` (the pickled dicts the
-base script loads from extracted/speecht5/mapping/, …base…py:40-49) or ``--random-init`` -- there is no
-network for ``from_pretrained``; audio decoding uses soundfile or scipy (librosa is not installed) and
-polyphase resampling to 16 kHz; ``-m text`` is refused (the text prenet is outside this hot path).
-With WORLD_SIZE > 1 the utterances are sharded over ranks (dp.shard_units); each rank writes the files of its
-own shard, so no embedding crosses the fabric unless --gather is given.
+Same flags (-m/--modality, -s/--split), same folder layout (extracted/<model>/<split>/<modality>/), the same
+per-utterance pickle and THE SAME BATCHES as the reference: ``batch_size = 2``, ``shuffle=False``, corpus order
+(…base…py:67-68).  Batch composition is part of the function -- GroupNorm statistics run over the padded axis, so an
+utterance encoded next to a longer one differs from the same utterance encoded alone -- and the
+reference's pairs (0,1), (2,3), ... are therefore kept at every world size: with WORLD_SIZE > 1 whole batches are dealt
+round-robin to the ranks (dp.shard_batches); each rank writes the files of its own batches, so no embedding crosses the
+fabric unless --gather is given.  ``--batch-size N`` / ``--bucket-by-length`` trade that identity for throughput
+(bigger batches; units sorted by length so that padding is minimal) and say so in their help text.
+
+What differs by necessity: weights come from ``--prenet-state-dict`` / ``--encoder-state-dict`` /
+``--text-prenet-state-dict`` (the pickled dicts the base script loads from extracted/speecht5/mapping/, …base…py:40-49)
+or ``--random-init`` -- there is no network for ``from_pretrained``; audio decoding uses soundfile or scipy (librosa is
+not installed) and the device polyphase resampler to 16 kHz; ``-m text`` (…base…py:79-93) needs the tokenizer files in a
+local directory.  Targets are one-hot over the reference's fixed 101 intent labels (``ALL_CLASSES``, …base…py:32-36),
+shipped as loco-asr_amd/data/slurp_intent_classes.txt, for every split alike.
 """
 from __future__ import annotations
 
@@ -52,8 +59,10 @@ def read_slurp_split(data_path: str, split: str):
     return items
 
 
-def load_audio_16k(path: str) -> np.ndarray:
-    """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56)."""
+def load_audio_16k(path: str):
+    """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56): files at another rate (Fisher:
+    8 kHz, podcasts: 44.1 kHz) are converted ON THE DEVICE by loco_op_resample (resample.py) and come back as CUDA tensors,
+    which the feature extractor pads on the device; 16 kHz files stay numpy arrays on the host."""
     try:
         import soundfile as sf
         x, sr = sf.read(path, dtype="float32", always_2d=True)
@@ -69,11 +78,23 @@ def load_audio_16k(path: str) -> np.ndarray:
         if x.ndim == 2:
             x = x.mean(axis=1)
     if sr != 16000:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), 16000)
-        x = resample_poly(x, 16000 // g, int(sr) // g).astype(np.float32)
+        return importlib.import_module("loco-asr_amd.resample").resample_to_16k(x, int(sr))
     return x
+
+
+CLASSES_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "slurp_intent_classes.txt")
+
+
+def load_classes(path=None):
+    """The reference's ALL_CLASSES (intent_classes.py, used at …base…py:32): the fixed 101 SLURP intent labels, the same for
+    every split -- never the labels that happen to occur in the split being extracted (train has 91 of them, train_synthetic
+    98: targets of different widths and index maps would result)."""
+    with open(path or CLASSES_FILE) as fh:
+        classes = [l.strip() for l in fh if l.strip()]
+    if len(classes) != 101 or len(set(classes)) != 101:
+        raise SystemExit(f"{path or CLASSES_FILE}: expected 101 distinct intent labels, found {len(classes)} "
+                         f"({len(set(classes))} distinct): IntentClassifier's output layer is Linear(768, 101)")
+    return classes
 
 
 def one_hot_encoder(classes):
@@ -81,7 +102,13 @@ def one_hot_encoder(classes):
     order = sorted(set(classes))
     index = {c: i for i, c in enumerate(order)}
     eye = np.eye(len(order), dtype=np.int64)
-    return lambda labels: np.stack([eye[index[l]] for l in labels])
+
+    def encode(labels):
+        unknown = [l for l in labels if l not in index]
+        if unknown:  # sklearn's LabelEncoder.transform raises ValueError("y contains previously unseen labels") here
+            raise ValueError(f"y contains previously unseen labels: {unknown}")
+        return np.stack([eye[index[l]] for l in labels])
+    return encode
 
 
 def load_state_dict_file(path):
@@ -112,10 +139,8 @@ def extract_text(args, items, classes, encode_labels, device, world, rank):
         except Exception as e:  # no hub access / no local files: say what is needed instead of a stack trace
             raise SystemExit(f"-m text needs the SpeechT5 tokenizer files (--tokenizer DIR with spm_char.model): {e}")
         tokenize = lambda idx: [np.asarray(tok(items[i][1])["input_ids"], dtype=np.int64) for i in idx]
-    mine = list(range(rank, len(items), world))
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
-        for k in range(0, len(mine), args.batch_size):
-            idx = mine[k:k + args.batch_size]
+        for idx in dp.shard_batches(len(items), args.batch_size, world, rank):  # the reference's batches, dealt whole
             seqs = tokenize(idx)
             T = max(len(q) for q in seqs)
             ids = np.full((len(seqs), T), 1, dtype=np.int64)  # padding="longest" with pad_token_id = 1
@@ -132,13 +157,21 @@ def main(argv=None):
     ap.add_argument("--split", "-s", choices=["train", "devel", "test", "train_synthetic"], required=True)
     ap.add_argument("--data-path", default="slurp")
     ap.add_argument("--out", default=os.path.join("extracted", "speecht5_base"))
-    ap.add_argument("--batch-size", type=int, default=16)
+    ap.add_argument("--batch-size", type=int, default=2,
+                    help="default 2 = the reference's batch_size (…base…py:67); batch composition changes the embeddings of padded "
+                         "utterances (GroupNorm over the padded axis), so other values are not bit-comparable with the reference")
+    ap.add_argument("--bucket-by-length", action="store_true",
+                    help="sort units by length and deal them to ranks longest first (minimal padding, balanced T^2 work) instead of "
+                         "the reference's corpus-order batches; changes which utterances share a batch")
     ap.add_argument("--prenet-state-dict", default="extracted/speecht5/mapping/speech_prenet_state_dict.pickle")
     ap.add_argument("--encoder-state-dict", default="extracted/speecht5/mapping/encoder_state_dict.pickle")
     ap.add_argument("--random-init", action="store_true", help="deterministic synthetic weights (no checkpoint available)")
     ap.add_argument("--synthetic", type=int, default=0, help="encode N seeded synthetic clips instead of a corpus")
     ap.add_argument("--synthetic-seconds", type=float, default=5.0)
-    ap.add_argument("--classes-file", default=None, help="one intent label per line (the reference's ALL_CLASSES)")
+    ap.add_argument("--synthetic-exact", action="store_true",
+                    help="every synthetic clip lasts exactly --synthetic-seconds (default: lengths drawn U[0.5, 1] x that, SURVEY.md 8d)")
+    ap.add_argument("--classes-file", default=None,
+                    help="one intent label per line; default: the reference's 101 ALL_CLASSES shipped with the package")
     ap.add_argument("--do-normalize", action="store_true")
     ap.add_argument("--normalize-on-device", action="store_true",
                     help="with --do-normalize: run zero_mean_unit_var_norm on the GPU right after the H2D copy instead of in numpy")
@@ -174,19 +207,17 @@ def main(argv=None):
     # ---- utterances
     if args.synthetic:
         n = int(args.synthetic_seconds * 16000)
-        lens = la.synth.mixed_lengths(args.synthetic, n)
-        items = [(f"synthetic-{i:06d}", "", None, 16000, f"class_{i % 101:03d}") for i in range(args.synthetic)]
-        classes = [f"class_{i:03d}" for i in range(101)]
+        lens = [n] * args.synthetic if args.synthetic_exact else la.synth.mixed_lengths(args.synthetic, n)
+        classes = load_classes(args.classes_file)
+        order = sorted(classes)
+        items = [(f"synthetic-{i:06d}", "", None, 16000, order[i % 101]) for i in range(args.synthetic)]
         fetch = lambda i: la.synth.clip(i, lens[i])
         lengths = lens
     else:
         items = read_slurp_split(args.data_path, args.split)
-        if args.classes_file:
-            classes = [l.strip() for l in open(args.classes_file) if l.strip()]
-        else:
-            classes = sorted({it[4] for it in items})
+        classes = load_classes(args.classes_file)
         fetch = lambda i: load_audio_16k(items[i][2])
-        lengths = [0] * len(items)  # unknown until decoded: keep corpus order within a rank
+        lengths = [0] * len(items)  # unknown until decoded
     if args.window_seconds > 0:
         # windows become the units: (id_wk, text, path, sr, label) with a fetch that slices the parent recording
         win = int(args.window_seconds * 16000)
@@ -224,18 +255,27 @@ def main(argv=None):
     processor = la.SpeechT5FeatureExtractorMI355X(do_normalize=args.do_normalize, pin_memory=True,
                                                   normalize_on_device=args.do_normalize and args.normalize_on_device)
 
-    shards = [dp.shard_units(lengths, world, r) if any(lengths) else list(range(r, len(items), world)) for r in range(world)]
-    mine = shards[rank]
-    n_rounds = (max(len(s) for s in shards) + args.batch_size - 1) // args.batch_size  # equal on all ranks: collectives line up
+    if args.bucket_by_length:
+        if not any(lengths):
+            lengths = [len(fetch(i)) for i in range(len(items))]  # one decoding pass to learn the lengths
+        shards = [dp.shard_units(lengths, world, r) for r in range(world)]
+        my_batches = [shards[rank][a:a + args.batch_size] for a in range(0, len(shards[rank]), args.batch_size)]
+        n_rounds = (max(len(s) for s in shards) + args.batch_size - 1) // args.batch_size
+    else:  # the reference's batches: corpus order, whole batches dealt round-robin
+        my_batches = dp.shard_batches(len(items), args.batch_size, world, rank)
+        n_rounds = dp.rounds(len(items), args.batch_size, world)  # equal on all ranks: collectives line up
+
     def host_batch(rnd):
         """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads."""
-        idx = mine[rnd * args.batch_size:(rnd + 1) * args.batch_size]
+        idx = my_batches[rnd] if rnd < len(my_batches) else []
         if not idx:
             return idx, None
         if pool is not None and args.window_seconds <= 0:  # the window cache of one decoded recording is not thread-safe
             clips = list(pool.map(fetch, idx))
         else:
             clips = [fetch(i) for i in idx]
+        if any(torch.is_tensor(c) for c in clips):  # some files were resampled on the device: the whole batch is padded there
+            clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
         return idx, processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
 
     from concurrent.futures import ThreadPoolExecutor

@@ -78,6 +78,24 @@ class SpeechT5FeatureExtractorMI355X:
         self.return_attention_mask = return_attention_mask
         self.pin_memory = pin_memory
 
+    def _device_batch(self, clips):
+        """padding="longest" for clips that live on the GPU: same contract (zero right-padding, int32 mask); do_normalize runs
+        there too (loco_op_normalize_waveform, HF feature_extraction_speecht5.py:119-138)."""
+        dev = clips[0].device
+        clips = [c.to(torch.float32).reshape(-1) for c in clips]
+        lmax = max(int(c.numel()) for c in clips)
+        x = torch.full((len(clips), lmax), float(self.padding_value), dtype=torch.float32, device=dev)
+        m = torch.zeros((len(clips), lmax), dtype=torch.int32, device=dev)
+        for i, c in enumerate(clips):
+            x[i, :c.numel()] = c
+            m[i, :c.numel()] = 1
+        if self.do_normalize:
+            normalize_waveform_(x, m, self.padding_value)
+        out = BatchFeature(input_values=x)
+        if self.return_attention_mask:
+            out["attention_mask"] = m
+        return out
+
     @staticmethod
     def zero_mean_unit_var_norm(x: np.ndarray) -> np.ndarray:
         return ((x - x.mean()) / np.sqrt(x.var() + 1e-7)).astype(np.float32)
@@ -89,7 +107,9 @@ class SpeechT5FeatureExtractorMI355X:
             raise ValueError(f"The model was trained at {self.sampling_rate} Hz; got sampling_rate={sampling_rate}.")
         if isinstance(audio, np.ndarray) and audio.ndim == 1 or torch.is_tensor(audio) and audio.dim() == 1:
             audio = [audio]
-        clips = [np.asarray(a, dtype=np.float32).reshape(-1) for a in audio]
+        if len(audio) and all(torch.is_tensor(a) and a.is_cuda for a in audio):
+            return self._device_batch(list(audio))  # clips already on the GPU (the device resampler's output): pad there
+        clips = [np.asarray(a.cpu() if torch.is_tensor(a) else a, dtype=np.float32).reshape(-1) for a in audio]
         if not clips:
             raise ValueError("empty batch")
         defer = self.do_normalize and self.normalize_on_device

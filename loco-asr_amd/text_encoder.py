@@ -152,11 +152,27 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
                 hs = [torch.empty_like(out) for _ in range(self.num_layers + 1)]
                 hs_ptrs = (C.c_void_p * (self.num_layers + 1))(*[t.data_ptr() for t in hs])
             stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-            _lib.check(self._lib.loco_forward_text(self._handle, C.c_void_p(ids32.data_ptr()),
-                                                   C.c_void_p(m.data_ptr()) if m is not None else None, B, T,
-                                                   C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
-                                                   C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream),
-                       "loco_forward_text")
+
+            def launch():
+                _lib.check(self._lib.loco_forward_text(self._handle, C.c_void_p(ids32.data_ptr()),
+                                                       C.c_void_p(m.data_ptr()) if m is not None else None, B, T,
+                                                       C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs,
+                                                       C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream),
+                           "loco_forward_text")
+
+            launch()
+            # numeric range of precision "f16x3" (include/loco_asr.h): same policy as the speech encoder's
+            self.last_range_fallback = False
+            policy = getattr(self, "range_policy", "fp32")
+            if policy != "off" and self.precision != "f32":
+                torch.cuda.current_stream(device).synchronize()
+                rc = self._lib.loco_forward_status(self._handle, None, 0)
+                if rc != 0:
+                    if policy == "raise":
+                        _lib.check(rc, "loco_forward_text")
+                    _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS["f32"]), "set_precision")
+                    launch()  # the same batch on the exact-fp32 kernels
+                    self.last_range_fallback = True
         self.last_frames = frames
         hidden = tuple(hs) if hs is not None else None
         if return_dict is False:

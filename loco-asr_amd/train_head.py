@@ -4,8 +4,13 @@ pre-extracted embeddings with the HIP head (intent_head.py), same flags (-m moda
 same folder conventions (extracted/speecht5[_base]/<split>/<modality>/ in; checkpoints/<version>/<modality>/
 <pooling>/speecht5_<pooling>_<modality>_{epoch_N,best,last}.pth and results/.../logs/results.txt out), same
 hyper-parameters (batch 16, Adam lr 1e-3 wd 1e-4, 100 epochs, patience 5; train_classifier.py:53,61-68) and
-the same early-stopping rule (:158-169).  Like the reference, validation doubles as the "test" loader
-(:56 wraps val_set).  With WORLD_SIZE > 1 each rank takes every W-th batch and gradients are all-reduced.
+the same early-stopping rule (:158-169), the two curves losses.png / accuracies.png (:177-196, when matplotlib is
+importable).  Like the reference, validation doubles as the "test" loader (:56 wraps val_set) and the final figures are
+divided by len(test_set) (:211-212) -- the `test` split is loaded for that (:37) and, when it does not exist, the
+validation size is used and said so.  With WORLD_SIZE > 1 every epoch's shuffled batches (same seeded permutation on
+every rank) are dealt round-robin and each rank LOADS ONLY ITS OWN batches (a rank-strided batch sampler: host I/O per
+rank is 1/W of the epoch); gradients are all-reduced; the up to W-1 batches of an incomplete last round are dropped so
+that the collectives line up.
 
     python loco-asr_amd/train_head.py -m audio -p attention -v base
     torchrun --standalone --nproc-per-node 8 loco-asr_amd/train_head.py -m audio -p attention -v base
@@ -44,6 +49,41 @@ def evaluate(model, loader, device, n_items):
     return loss / n_items, acc / n_items
 
 
+def epoch_batches(n_items, batch_size, world, rank, generator):
+    """This rank's batches of one epoch: the epoch's seeded permutation (what DataLoader(shuffle=True, generator=g) draws,
+    train_classifier.py:54) cut into batches of `batch_size`; batches rank, rank+W, ... of the first floor(nb/W)*W (all of
+    them at W = 1).  Returns (global batch indices, index lists).  Every rank must call it once per epoch with an identically
+    seeded generator."""
+    perm = torch.randperm(n_items, generator=generator).tolist()
+    batches = [perm[a:a + batch_size] for a in range(0, len(perm), batch_size)]
+    stop = len(batches) if world == 1 else (len(batches) // world) * world
+    ids = list(range(rank, stop, world))
+    return ids, [batches[i] for i in ids]
+
+
+def write_curves(curves, plots_folder):
+    """losses.png / accuracies.png of train_classifier.py:177-196; skipped (with a note) where matplotlib is missing."""
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        print("matplotlib is not installed: curves not plotted")
+        return
+    os.makedirs(plots_folder, exist_ok=True)
+    for name, a, b, ylabel, title in (("losses.png", "loss", "val_loss", "Loss", "Training and Validation Loss"),
+                                      ("accuracies.png", "acc", "val_acc", "Accuracy", "Training and Validation Accuracy")):
+        plt.figure()
+        plt.plot(curves[a], label="Training " + ylabel)
+        plt.plot(curves[b], label="Validation " + ylabel)
+        plt.xlabel("Epoch")
+        plt.ylabel(ylabel)
+        plt.title(title)
+        plt.legend()
+        plt.savefig(os.path.join(plots_folder, name))
+        plt.close()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description="Train an Intent Classifier with SpeechT5 embeddings from SLURP dataset (MI355X)")
     ap.add_argument("--modality", "-m", choices=["text", "audio"], required=True)
@@ -72,9 +112,19 @@ def main(argv=None):
     train_set = ConcatDataset(sets)
     val_set = sink.EmbeddingsTargets(folder, args.modality, "devel")
     print(f"Train set: {len(train_set)}, Val set: {len(val_set)}")
+    n_test, test_note = len(val_set), " (no test split on disk: divided by the validation size)"
+    if os.path.isdir(os.path.join(folder, "test", args.modality)):
+        n_test, test_note = len(sink.EmbeddingsTargets(folder, args.modality, "test")), ""
+        print(f"Test set: {n_test}")
     g = torch.Generator().manual_seed(0)  # identical shuffles on every rank
-    train_loader = DataLoader(train_set, batch_size=16, shuffle=True, collate_fn=collate_fn, generator=g)
-    val_loader = DataLoader(val_set, batch_size=16, shuffle=False, collate_fn=collate_fn)
+    batch_size = 16
+    n_train_batches = (len(train_set) + batch_size - 1) // batch_size
+
+    def my_epoch_loader():
+        ids, mine = epoch_batches(len(train_set), batch_size, world, rank, g)
+        return ids, DataLoader(train_set, batch_sampler=mine, collate_fn=collate_fn)  # only this rank's batches are read from disk
+
+    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
 
     model = la.IntentClassifierMI355X(method=args.pooling, lr=0.001, weight_decay=0.0001).to(device)
     save_folder = os.path.join(args.out_root, "checkpoints", args.version, args.modality, args.pooling)
@@ -85,23 +135,25 @@ def main(argv=None):
     tag = f"speecht5_{args.pooling}_{args.modality}"
     text = "Results\n"
     best, stale = float("inf"), 0
+    curves = {"loss": [], "val_loss": [], "acc": [], "val_acc": []}
     print("Training started...")
     for epoch in range(args.epochs):
-        epoch_loss, acc_train, n_batches = 0.0, 0.0, 0
-        for i, (_, data, target) in enumerate(train_loader):
-            if i % world != rank:  # data parallel: every W-th batch is this rank's; ranks with no batch left stop together
-                continue
-            if (i // world) * world + world > len(train_loader) and world > 1:
-                break
+        epoch_loss, acc_train, n_batches, n_seen = 0.0, 0.0, 0, 0
+        batch_ids, train_loader = my_epoch_loader()
+        for i, (_, data, target) in zip(batch_ids, train_loader):
             loss, pred = model.train_step(data.to(device), target.to(device))
             epoch_loss += float(loss)
             acc_train += float((pred.argmax(1) == target.to(device).argmax(1)).float().sum())
             n_batches += 1
+            n_seen += data.shape[0]
             if (i + 1) % 200 == 0 and rank == 0:
-                print(f"Epoch [{epoch+1}/{args.epochs}], Iteration [{i+1}/{len(train_loader)}], Loss: {float(loss):.4f}")
+                print(f"Epoch [{epoch+1}/{args.epochs}], Iteration [{i+1}/{n_train_batches}], Loss: {float(loss):.4f}")
+                text += f"Epoch [{epoch+1}/{args.epochs}], Iteration [{i+1}/{n_train_batches}], Loss: {float(loss):.4f}\n"
         epoch_loss /= max(1, n_batches)
-        acc_train /= max(1, n_batches * 16)
+        acc_train /= max(1, n_seen)
         val_loss, acc_val = evaluate(model, val_loader, device, len(val_set))
+        for k, v in (("loss", epoch_loss), ("val_loss", val_loss), ("acc", acc_train), ("val_acc", acc_val)):
+            curves[k].append(v)
         line = (f"Epoch [{epoch+1}/{args.epochs}], Training Loss: {epoch_loss:.4f}, Training accuracy: {round(acc_train*100, 2)}, "
                 f"Validation Loss: {val_loss:.4f}, Validation accuracy: {acc_val*100:.2f}")
         print(line)
@@ -121,13 +173,19 @@ def main(argv=None):
         torch.save(model.state_dict(), os.path.join(save_folder, f"{tag}_last.pth"))
         with open(os.path.join(logs_folder, "results.txt"), "w") as fh:
             fh.write(text)
+        write_curves(curves, os.path.join(os.path.dirname(logs_folder), "plots"))
     print("Training done!")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()  # rank 0 has finished writing *_best.pth before any rank reads it
     model = la.IntentClassifierMI355X(method=args.pooling).to(device)
     model.load_state_dict(torch.load(os.path.join(save_folder, f"{tag}_best.pth")))
-    print("Evaluating model on test set")
-    tl, ta = evaluate(model, val_loader, device, len(val_set))
+    print("Evaluating model on test set" + test_note)
+    # the reference iterates the validation loader here and divides by len(test_set) (train_classifier.py:56, 211-212)
+    tl, ta = evaluate(model, val_loader, device, n_test)
     print(f"Test Loss: {tl:.4f}")
     print(f"Test Accuracy: {ta*100:.2f}")
+    print("Evaluation done!")
     return tl, ta
 
 

@@ -1,7 +1,8 @@
 """The N > 1 path on CPU: two gloo ranks shard a ragged list of clips, encode their shards and gather.
 The encode function here is the CPU oracle (tests may use it as the checker's stand-in for the GPU forward);
-what is under test is the sharding, the padding to the global T_max, the ordering and the single large
-all_gather_into_tensor -- the code bench.py and extract.py run over RCCL."""
+what is under test is the sharding -- WHOLE reference batches (corpus-order pairs, …base…py:67-68) dealt to ranks, so that
+every utterance keeps the batch mate it has in the single-process reference loop -- the padding to the global T_max, the
+ordering and the single large all_gather_into_tensor: the code bench.py and extract.py run over RCCL."""
 import importlib
 import os
 import socket
@@ -15,7 +16,7 @@ import torch.multiprocessing as mp
 
 from conftest import ROOT
 
-LENGTHS = [16000, 9000, 12000, 4000, 16000]
+LENGTHS = [16000, 9000, 12000, 4000, 16000, 7000, 11000]  # ragged, 7 clips: pairs (0,1) (2,3) (4,5) and a single (6)
 
 
 def _free_port():
@@ -42,11 +43,17 @@ def _worker(rank, world, port, out_dir):
         b = fe(audio=cs, sampling_rate=16000)
         return b["input_values"], b["attention_mask"]
 
+    seen = []
+
     def encode(x, m):
+        seen.append(tuple(int(v) for v in m.sum(1)))  # the valid lengths of the batch this rank was handed
         return oracle.encode(x, m, sd)
 
-    res = dp.encode_sharded(encode, clips, make_batch, torch.device("cpu"), max_batch=2)
+    res = dp.encode_sharded(encode, clips, make_batch, torch.device("cpu"))  # default: the reference's batches of 2
     assert all(r is not None for r in res)
+    # pair preservation: every batch this rank encoded is one of the reference's consecutive pairs, whole
+    pairs = [tuple(LENGTHS[a:a + 2]) for a in range(0, len(LENGTHS), 2)]
+    assert seen == pairs[rank::world], (rank, seen)
     # equal-shape fast path used by bench.py
     loc = torch.full((2, 3, 4), float(rank))
     g = dp.all_gather_embeddings(loc)
@@ -64,23 +71,23 @@ def test_two_rank_sharded_encode_matches_single_process(tmp_path):
     assert len(r0) == len(r1) == len(LENGTHS)
     for a, b in zip(r0, r1):  # every rank ends with the same gathered result
         assert torch.equal(a, b)
-    # and each clip equals what its owner batch produces in a single process
+    # and each clip equals what the single-process reference loop produces: DataLoader(batch_size=2, shuffle=False) pairs,
+    # written out here from the corpus order (not from the package's sharding helpers)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     la = importlib.import_module("loco-asr_amd")
-    dp = importlib.import_module("loco-asr_amd.dp")
     import speecht5_oracle as oracle
     sd = la.synth.encoder_state_dict(0, layers=1)
     clips = [la.synth.clip(i, n) for i, n in enumerate(LENGTHS)]
     fe = la.SpeechT5FeatureExtractorMI355X()
-    for r in range(world):
-        mine = dp.shard_units(LENGTHS, world, r)
-        for c0 in range(0, len(mine), 2):
-            ids = mine[c0:c0 + 2]
-            b = fe(audio=[clips[i] for i in ids], sampling_rate=16000)
-            ref = oracle.encode(b["input_values"], b["attention_mask"], sd)
-            for row, gid in enumerate(ids):
-                assert r0[gid].shape == ref[row].shape
-                assert torch.allclose(r0[gid], ref[row], atol=1e-5)
+    for ids in ([0, 1], [2, 3], [4, 5], [6]):
+        b = fe(audio=[clips[i] for i in ids], sampling_rate=16000)
+        ref = oracle.encode(b["input_values"], b["attention_mask"], sd)
+        for row, gid in enumerate(ids):
+            assert r0[gid].shape == ref[row].shape
+            assert torch.allclose(r0[gid], ref[row], atol=1e-5)
+    # batch composition matters: clip 1 encoded alone (no padding) differs from clip 1 as the short member of pair (0,1)
+    alone = oracle.encode(clips[1][None], None, sd)[0]
+    assert not torch.allclose(r0[1][:alone.shape[0]], alone, atol=1e-3)
 
 
 def _overlap_worker(rank, world, port):

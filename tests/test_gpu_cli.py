@@ -13,23 +13,22 @@ pytestmark = pytest.mark.gpu
 
 
 def test_extract_cli_synthetic(tmp_path, oracle):
+    """Default flags = the reference's loop: batch_size 2, shuffle=False (…base…py:67-68).  A ragged 7-clip corpus must give,
+    per utterance, what the oracle gives on the reference's pairs (0,1), (2,3), (4,5), (6) -- built here from the corpus
+    order itself, not from the package's sharding helpers."""
     la = importlib.import_module("loco-asr_amd")
     extract = importlib.import_module("loco-asr_amd.extract")
     sink = importlib.import_module("loco-asr_amd.sink")
     out = str(tmp_path / "extracted" / "speecht5_base")
-    extract.main(["-m", "audio", "-s", "devel", "--synthetic", "5", "--synthetic-seconds", "1.5", "--random-init",
-                  "--batch-size", "2", "--out", out])
+    extract.main(["-m", "audio", "-s", "devel", "--synthetic", "7", "--synthetic-seconds", "1.5", "--random-init", "--out", out])
     ds = sink.EmbeddingsTargets(out, modality="audio", split="devel")
-    assert len(ds) == 5
+    assert len(ds) == 7
     n = int(1.5 * 16000)
-    lens = la.synth.mixed_lengths(5, n)
+    lens = la.synth.mixed_lengths(7, n)
+    assert len(set(lens)) == 7  # ragged: every pair pads its shorter member
     sd = la.synth.encoder_state_dict(0)
     fe = la.SpeechT5FeatureExtractorMI355X()
-    # batches are formed over the corpus order dealt by dp.shard_units (single rank: longest first)
-    dp = importlib.import_module("loco-asr_amd.dp")
-    order = dp.shard_units(lens, 1, 0)
-    for b0 in range(0, 5, 2):
-        idx = order[b0:b0 + 2]
+    for idx in ([0, 1], [2, 3], [4, 5], [6]):
         b = fe(audio=[la.synth.clip(i, lens[i]) for i in idx], sampling_rate=16000)
         ref = oracle.encode(b["input_values"], b["attention_mask"], sd)
         for row, i in enumerate(idx):
@@ -39,6 +38,11 @@ def test_extract_cli_synthetic(tmp_path, oracle):
             rel = np.linalg.norm(d["embedding"] - ref[row].numpy()) / np.linalg.norm(ref[row].numpy())
             assert rel < 1e-4
             assert d["target"].shape == (101,) and d["target"].sum() == 1 and d["target"][i % 101] == 1
+    # --bucket-by-length regroups the clips (longest first): same files, but the padded clips see other batch mates
+    out2 = str(tmp_path / "bucketed")
+    extract.main(["-m", "audio", "-s", "devel", "--synthetic", "7", "--synthetic-seconds", "1.5", "--random-init", "--bucket-by-length",
+                  "--out", out2])
+    assert sorted(os.listdir(os.path.join(out2, "devel", "audio"))) == sorted(os.listdir(os.path.join(out, "devel", "audio")))
 
 
 def test_extract_cli_text_modality(tmp_path, oracle):
@@ -127,3 +131,37 @@ def test_extract_cli_windows(tmp_path, oracle):
     # windows of equal length batched together are independent units
     assert d["embedding"].shape == ref.shape
     assert np.linalg.norm(d["embedding"] - ref) / np.linalg.norm(ref) < 1e-4
+
+
+def test_extract_cli_one_hour_recording_in_ten_minute_windows(tmp_path, oracle):
+    """BASELINE.json configs[3] on one GPU at its real size: one 60-minute recording through --window-seconds 600 -> six units of
+    T = 29 999 frames, <id>_w000 ... _w005, encoded in the reference's batches of two.  Chain of evidence for the last pair:
+    the pickles equal a direct forward of the same two windows bit for bit, and that forward's last layer reproduces the fp64
+    row oracle on window 5 (keys over all 29 999 frames)."""
+    la = importlib.import_module("loco-asr_amd")
+    extract = importlib.import_module("loco-asr_amd.extract")
+    from gpu_util import model, rel_l2
+    out = str(tmp_path / "podcast")
+    extract.main(["-m", "audio", "-s", "test", "--synthetic", "1", "--synthetic-seconds", "3600", "--synthetic-exact", "--random-init",
+                  "--window-seconds", "600", "--out", out])
+    files = sorted(os.listdir(os.path.join(out, "test", "audio")))
+    assert files == [f"synthetic-000000_w{k:03d}_embedding_and_target.pickle" for k in range(6)]
+    emb = {}
+    for k in (0, 4, 5):
+        with open(os.path.join(out, "test", "audio", files[k]), "rb") as fh:
+            d = pickle.load(fh)
+        assert d["id"] == f"synthetic-000000_w{k:03d}" and d["embedding"].shape == (29999, 768) and d["embedding"].dtype == np.float32
+        assert np.isfinite(d["embedding"]).all() and d["target"].shape == (101,)
+        emb[k] = d["embedding"]
+    assert not np.array_equal(emb[0], emb[5])
+    win = 600 * 16000
+    rec = la.synth.clip(0, 6 * win)
+    m, sd = model()
+    pair = torch.from_numpy(np.stack([rec[4 * win:5 * win], rec[5 * win:6 * win]])).cuda()
+    res = m.speecht5.encoder(input_values=pair, attention_mask=torch.ones_like(pair, dtype=torch.int32), output_hidden_states=True)
+    y = res.last_hidden_state.cpu().numpy()
+    assert np.array_equal(y[0], emb[4]) and np.array_equal(y[1], emb[5])
+    rows = [0, 1, 159, 160, 161, 15000, 29838, 29998]
+    pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
+    ref = oracle.encoder_layer_rows(res.hidden_states[11][1].cpu(), rows, 29999, sd, "wrapped_encoder.layers.11.", pe_k)
+    assert rel_l2(emb[5][rows], ref) < 1e-5

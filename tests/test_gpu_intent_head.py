@@ -116,6 +116,50 @@ def test_head_on_real_encoder_output():
     assert rel_l2(head(emb), ref(emb.cpu()).detach()) < 2e-5
 
 
+def test_configs4_head_training_step_on_real_encoder_output():
+    """BASELINE.json configs[4] at the head's real operating point: [16, T, 768] embeddings produced by the full 12-layer
+    encoder for 16 ragged 30 s clips, encoded in the reference's pairs (…base…py:67-68) so that every embedding carries the
+    padded frames of its pair, zero-padded to the longest by the training collate_fn (train_classifier.py:47-51); then logits,
+    loss, every gradient and three Adam steps of the HIP head against the torch oracle (itself pinned to the reference's
+    IntentClassifier by fixture g8), for the three pooling modes."""
+    from gpu_util import model
+    from torch.nn.utils.rnn import pad_sequence
+    m, _ = model()
+    enc = m.speecht5.encoder
+    lens = la.synth.mixed_lengths(16, 480000, seed=5)
+    embs = []
+    for a in range(0, 16, 2):
+        x, msk = la.synth.batch(lens[a:a + 2], first_index=200 + a)
+        y = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda()).last_hidden_state
+        embs += [y[0].clone(), y[1].clone()]
+    assert not enc.last_range_fallback
+    data = pad_sequence(embs, batch_first=True)  # [16, Tmax, 768] on the GPU, zero rows beyond each utterance's file length
+    assert data.shape[0] == 16 and data.shape[2] == 768 and data.shape[1] == la.synth.conv_out_length(max(lens))
+    cls = torch.arange(16) * 6 % 101
+    target = torch.eye(101, dtype=torch.int64)[cls]
+    for method in ("average", "max", "attention"):
+        ref, head = paired(method, seed=11)
+        pred = ref(data.cpu())
+        assert rel_l2(head(data), pred.detach()) < 2e-5
+        loss = torch.nn.CrossEntropyLoss()(pred.squeeze(1), target.float())
+        loss.backward()
+        gl, _, grads = head.loss_and_grads(data, target.cuda())
+        assert abs(float(gl) - float(loss.detach())) < 2e-5 * max(1.0, abs(float(loss.detach())))
+        gw = grads[768:768 + 101 * 768].view(101, 768).cpu()
+        assert rel_l2(gw, ref.classifier[0].weight.grad) < 5e-5 and rel_l2(grads[768 + 101 * 768:].cpu(), ref.classifier[0].bias.grad) < 5e-5
+        if method == "attention":
+            assert rel_l2(grads[:768].cpu(), ref.q.grad.reshape(-1)) < 1e-4
+        ref.zero_grad(set_to_none=True)
+        opt = torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=0.0001)
+        for step in range(3):
+            lr_, _ = iho.train_step(ref, opt, data.cpu(), target)
+            lg, _ = head.train_step(data, target.cuda())
+            assert abs(float(lg) - float(lr_)) < 5e-5 * max(1.0, abs(float(lr_))), (method, step)
+        sd = head.state_dict()
+        assert rel_l2(sd["classifier.0.weight"], ref.classifier[0].weight.detach()) < 1e-5
+        assert rel_l2(sd["q"], ref.q.detach()) < 1e-5
+
+
 def test_errors():
     _, head = paired("max")
     with pytest.raises(ValueError):

@@ -70,3 +70,75 @@ def test_masked_long_clip_matches_row_oracle(oracle):
     rows = [0, 200, nv - 1, nv, nv + 200, 29998]
     ref = oracle.encoder_layer_rows(out.hidden_states[5][1].cpu(), rows, nv, sd, "wrapped_encoder.layers.5.", pe_k)
     assert rel_l2(out.hidden_states[6][1, rows], ref) < 1e-5
+
+
+# ---- BASELINE.json configs[2] at its stated size: 10 minutes x BATCH 4 --------------------------------------------------------
+# [4, 9 600 000] samples -> [4, 29 999, 768]: 30 GB of workspace and four times the grids of the single-clip run above.  The
+# probe rows are taken on clip 3 -- the LAST clip, i.e. the far end of every buffer -- with each stage's input read back from
+# the GPU run and its output rows recomputed by the oracle in fp64.
+
+@pytest.fixture(scope="module")
+def long_b4():
+    m, sd = model()
+    x, _ = la.synth.batch([L10] * 4, first_index=40)
+    xs = torch.from_numpy(x).cuda()
+    st = {}
+    enc = m.speecht5.encoder
+    out = enc(input_values=xs, output_hidden_states=True, stage_taps=st)
+    torch.cuda.synchronize()
+    assert not enc.last_range_fallback
+    return x, xs, out, st, sd, enc
+
+
+def test_b4_shapes_finiteness_and_rerun_bit_identity(long_b4):
+    x, xs, out, st, _, enc = long_b4
+    y = out.last_hidden_state
+    assert tuple(y.shape) == (4, 29999, 768) and len(out.hidden_states) == 13
+    assert bool(torch.isfinite(y).all()) and st["frames"].cpu().tolist() == [29999] * 4
+    # the production schedule (no hidden states: two half-batches of two clips on two streams) reproduces the in-order pass
+    # bit for bit, and so does a second run of it
+    a = enc(input_values=xs).last_hidden_state
+    b = enc(input_values=xs).last_hidden_state
+    torch.cuda.synchronize()
+    assert torch.equal(a, y) and torch.equal(a, b)
+    # the four clips are different signals: no clip is a copy of another (a stride bug would make them so)
+    assert not torch.equal(y[3], y[2]) and not torch.equal(y[3], y[0])
+
+
+def test_b4_last_clip_conv_stack_and_pos_conv(long_b4, oracle):
+    x, _, _, st, sd, _ = long_b4
+    for lo, hi in ((0, 6), (15000, 15005), (29994, 29999)):
+        ref = oracle.feature_encoder_window(torch.from_numpy(x[3]), sd, lo, hi)
+        assert rel_l2(st["conv_stack"][3, lo:hi], ref) < 1e-5
+    ref = oracle.pos_conv_rows(st["feature_projection"][3].cpu(), ROWS, 29999, sd)
+    assert rel_l2(st["prenet"][3, ROWS], ref) < 1e-5
+
+
+@pytest.mark.parametrize("layer", [0, 11])
+def test_b4_last_clip_encoder_layer_rows(long_b4, oracle, layer):
+    _, _, out, _, sd, _ = long_b4
+    pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
+    xin = out.hidden_states[layer][3].cpu()
+    ref = oracle.encoder_layer_rows(xin, ROWS, None, sd, f"wrapped_encoder.layers.{layer}.", pe_k)
+    assert rel_l2(out.hidden_states[layer + 1][3, ROWS], ref) < 1e-5
+
+
+def test_b4_ragged_short_clip_at_the_far_end(oracle):
+    """Three 10-minute clips and a 4-minute one at index 3: its keys beyond its own frame count are masked for every query,
+    its GroupNorm statistics run over the padded axis, and its rows are the last ones of every buffer."""
+    m, sd = model()
+    lens = [L10, L10, L10, 3_840_000]
+    x, msk = la.synth.batch(lens, first_index=60)
+    enc = m.speecht5.encoder
+    st = {}
+    out = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda(), output_hidden_states=True,
+              stage_taps=st)
+    nv = la.synth.conv_out_length(lens[3])
+    assert enc.last_frames.cpu().tolist() == [29999, 29999, 29999, nv] and bool(torch.isfinite(out.last_hidden_state).all())
+    ref = oracle.feature_encoder_window(torch.from_numpy(x[3]), sd, nv - 3, nv + 3)  # across the end of the real audio
+    assert rel_l2(st["conv_stack"][3, nv - 3:nv + 3], ref) < 1e-5
+    pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
+    rows = [0, 200, nv - 1, nv, nv + 200, 29998]
+    for layer in (0, 11):
+        ref = oracle.encoder_layer_rows(out.hidden_states[layer][3].cpu(), rows, nv, sd, f"wrapped_encoder.layers.{layer}.", pe_k)
+        assert rel_l2(out.hidden_states[layer + 1][3, rows], ref) < 1e-5

@@ -107,6 +107,53 @@ def test_shard_units_balances_and_partitions():
     assert (5 in s0) != (0 in s0)
 
 
+def test_shard_batches_keeps_the_reference_pairs():
+    """DataLoader(batch_size=2, shuffle=False) forms (0,1), (2,3), ...; under DP whole pairs are dealt, never split or re-paired."""
+    for n in (1, 2, 7, 8, 13):
+        ref_pairs = [list(range(a, min(n, a + 2))) for a in range(0, n, 2)]
+        assert dp.corpus_batches(n, 2) == ref_pairs
+        for world in (1, 2, 3, 8):
+            dealt = [dp.shard_batches(n, 2, world, r) for r in range(world)]
+            assert sorted(b for d in dealt for b in d) == ref_pairs
+            assert all(b in ref_pairs for d in dealt for b in d)
+            assert max(len(d) for d in dealt) == dp.rounds(n, 2, world)
+            assert max(map(len, dealt)) - min(map(len, dealt)) <= 1
+
+
+def test_intent_targets_use_the_fixed_101_classes_for_every_split(tmp_path):
+    """targets are one-hot over the reference's ALL_CLASSES (…base…py:32-36), whatever labels a split contains."""
+    classes = extract.load_classes()
+    assert len(classes) == 101 and len(set(classes)) == 101 and "alarm_set" in classes
+    enc = extract.one_hot_encoder(classes)
+    train_labels, devel_labels = ["alarm_set", "weather_query"], ["weather_query", "qa_factoid", "alarm_set"]
+    a, b = enc(train_labels), enc(devel_labels)
+    assert a.shape == (2, 101) and b.shape == (3, 101) and a.dtype == np.int64
+    assert (a[0] == b[2]).all() and (a[1] == b[0]).all()  # same label -> same column in every split
+    assert int(a[0].argmax()) == sorted(classes).index("alarm_set")  # LabelEncoder sorts
+    with pytest.raises(ValueError, match="unseen"):
+        enc(["not_an_intent"])
+    bad = tmp_path / "classes.txt"
+    bad.write_text("a\nb\n")
+    with pytest.raises(SystemExit, match="101"):
+        extract.load_classes(str(bad))
+
+
+def test_train_head_rank_strided_batches():
+    """Under DP each rank reads only its own batches of the epoch's permutation; together they are the first floor(nb/W)*W."""
+    th = importlib.import_module("loco-asr_amd.train_head")
+    n, bs = 103, 16
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).tolist()
+    full = [perm[a:a + bs] for a in range(0, n, bs)]  # 7 batches, the last one short
+    ids, b = th.epoch_batches(n, bs, 1, 0, torch.Generator().manual_seed(0))
+    assert ids == list(range(7)) and b == full
+    for world in (2, 3, 8):
+        got = [th.epoch_batches(n, bs, world, r, torch.Generator().manual_seed(0)) for r in range(world)]
+        assert len({len(i) for i, _ in got}) == 1  # same number of steps on every rank
+        merged = sorted((i, tuple(x)) for ids_, bs_ in got for i, x in zip(ids_, bs_))
+        keep = (7 // world) * world
+        assert merged == [(i, tuple(full[i])) for i in range(keep)]
+
+
 def test_slurp_reader_contract(tmp_path):
     root = tmp_path / "slurp"
     (root / "dataset" / "slurp").mkdir(parents=True)
