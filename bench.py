@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the short un-profiled run of the library's default schedule (two half-batches on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 only: create the RCCL process group of one rank anyway and issue the per-step all_gather_into_tensor on "
+                         "the device embeddings (what every rank does at N > 1), then check the gathered tensor against the local one")
     ap.add_argument("--cpu-sample-clips", type=int, default=8,
                     help="clips of the same workload the CPU oracle is timed on (1 warm-up + --cpu-reps timed passes, median)")
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -159,8 +162,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if args.force_collective and "RANK" not in os.environ:  # started without the launcher: a group of one rank all the same
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     la = importlib.import_module("loco-asr_amd")
@@ -179,6 +185,7 @@ def main():
     x = torch.from_numpy(x_np).to(dev)
     m = torch.from_numpy(m_np).to(dev)
 
+    dp.FORCE_COLLECTIVE = bool(args.force_collective)
     gatherer = dp.OverlappedGather()
 
     def step():
@@ -209,6 +216,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert gathered.shape[0] == world * B
+    if args.force_collective and world == 1:  # the collective really ran (RCCL, device tensors) and returned the rank's own rows
+        assert gathered.data_ptr() != y.data_ptr() and torch.equal(gathered, y), "all_gather_into_tensor at world size 1 changed the embeddings"
     # the default range policy ("fp32": re-run out-of-range batches on the exact-fp32 kernels) was active; a re-run inside the
     # timed region would make `value` a mixed-precision figure -- refuse to report one
     if enc.last_range_fallback:
@@ -242,7 +251,9 @@ def main():
             "precision": args.precision, "range_policy": enc.range_policy, "data": "synthetic",
             "config": {"workload": workload_label(args.clip_seconds, B),
                        "clip_seconds": args.clip_seconds, "batch_per_gpu": B, "global_batch": B * world, "frames_per_clip": T,
-                       "parallelism": f"dp{world}", "collective": "all_gather(embeddings)" if world > 1 else "none"},
+                       "parallelism": f"dp{world}",
+                       "collective": "all_gather(embeddings)" if world > 1 else
+                                     ("all_gather(embeddings), forced in a process group of one rank and checked" if args.force_collective else "none")},
             "whole_path_tflops": round(whole, 2),
             "roofline": roofline, "kernels": kernels,
         }
@@ -312,7 +323,7 @@ def main():
             result["embed_rel_l2"] = rel
             result["speedup_vs_cpu_baseline"] = round(value / (nc * T / cpu_s), 1)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -71,16 +71,28 @@ def window_units(lengths: Sequence[int], window: int, min_samples: int = 400) ->
     return units
 
 
+# Set (or LOCO_FORCE_COLLECTIVE=1) to issue the collectives even in a process group of ONE rank: a one-GPU box can then run
+# the real RCCL all_gather_into_tensor on device tensors next to the encoder's streams (tests/test_gpu_rccl_world1.py,
+# bench.py --force-collective).  Without a process group there is nothing to issue and the flag is ignored.
+FORCE_COLLECTIVE = False
+
+
 def _world(group=None) -> Tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_world_size(group), dist.get_rank(group)
     return 1, 0
 
 
+def _skip_collective(world: int) -> bool:
+    import os
+    forced = FORCE_COLLECTIVE or os.environ.get("LOCO_FORCE_COLLECTIVE") == "1"
+    return world == 1 and not (forced and dist.is_available() and dist.is_initialized())
+
+
 def all_gather_embeddings(local: torch.Tensor, group=None) -> torch.Tensor:
     """[B_loc, T, D] on every rank (same shape everywhere) -> [W*B_loc, T, D]; ONE collective."""
     world, _ = _world(group)
-    if world == 1:
+    if _skip_collective(world):
         return local
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
@@ -101,7 +113,7 @@ class OverlappedGather:
 
     def submit(self, local: torch.Tensor):
         world, _ = _world(self.group)
-        if world == 1:
+        if _skip_collective(world):
             self.result = local
             return
         self.finish()
@@ -130,7 +142,7 @@ def gather_ragged(local: torch.Tensor, local_ids: Sequence[int], n_total: int, g
     n_total tensors [T_rank(i), D] (padded rows as the owning rank computed them -- the reference keeps
     padded frames, …base…py:109-113) in global order, identical on every rank."""
     world, rank = _world(group)
-    if world == 1:
+    if _skip_collective(world):
         res = [None] * n_total
         for row, gid in enumerate(local_ids):
             res[gid] = local[row]

@@ -137,27 +137,51 @@ def test_configs4_head_training_step_on_real_encoder_output():
     assert data.shape[0] == 16 and data.shape[2] == 768 and data.shape[1] == la.synth.conv_out_length(max(lens))
     cls = torch.arange(16) * 6 % 101
     target = torch.eye(101, dtype=torch.int64)[cls]
+    xc = data.cpu()
     for method in ("average", "max", "attention"):
-        ref, head = paired(method, seed=11)
-        pred = ref(data.cpu())
-        assert rel_l2(head(data), pred.detach()) < 2e-5
-        loss = torch.nn.CrossEntropyLoss()(pred.squeeze(1), target.float())
-        loss.backward()
+        torch.manual_seed(11)
+        ref = iho.IntentClassifierOracle(method)
+        with torch.no_grad():
+            ref.q.mul_(30.0)  # |x_t| ~ 28 on LayerNorm'd embeddings: logits x.q of a few units -> attention weights far from uniform
+        head = la.IntentClassifierMI355X(method)
+        head.load_state_dict(ref.state_dict())
+        head = head.to("cuda")
+        # truth = the oracle in fp64; the fp32 oracle beside it shows how much fp32 itself can lose on T = 1499 frames (the query
+        # gradient of attention pooling is a sum with heavy cancellation), and bounds what is asked of the HIP head
+        ref64 = iho.IntentClassifierOracle(method).double()
+        ref64.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+        g32, g64 = {}, {}
+        for model_, x_, store in ((ref, xc, g32), (ref64, xc.double(), g64)):
+            pred = model_(x_)
+            loss = torch.nn.CrossEntropyLoss()(pred.squeeze(1), target.to(x_.dtype))
+            loss.backward()
+            store.update(logits=pred.detach(), loss=float(loss), gw=model_.classifier[0].weight.grad, gb=model_.classifier[0].bias.grad,
+                         gq=model_.q.grad.reshape(-1) if model_.q.grad is not None else None)
+
+        def bar(key, floor):
+            return max(floor, 3.0 * rel_l2(g32[key], g64[key]))
+
+        assert rel_l2(head(data), g64["logits"]) < bar("logits", 2e-5)
         gl, _, grads = head.loss_and_grads(data, target.cuda())
-        assert abs(float(gl) - float(loss.detach())) < 2e-5 * max(1.0, abs(float(loss.detach())))
-        gw = grads[768:768 + 101 * 768].view(101, 768).cpu()
-        assert rel_l2(gw, ref.classifier[0].weight.grad) < 5e-5 and rel_l2(grads[768 + 101 * 768:].cpu(), ref.classifier[0].bias.grad) < 5e-5
+        assert abs(float(gl) - g64["loss"]) < 2e-5 * max(1.0, abs(g64["loss"]))
+        assert rel_l2(grads[768:768 + 101 * 768].view(101, 768).cpu(), g64["gw"]) < bar("gw", 5e-5)
+        assert rel_l2(grads[768 + 101 * 768:].cpu(), g64["gb"]) < bar("gb", 5e-5)
         if method == "attention":
-            assert rel_l2(grads[:768].cpu(), ref.q.grad.reshape(-1)) < 1e-4
+            e_gpu, e_f32 = rel_l2(grads[:768].cpu(), g64["gq"]), rel_l2(g32["gq"], g64["gq"])
+            print(f"attention-pooling query gradient on [16, {data.shape[1]}, 768]: HIP head {e_gpu:.2e}, torch fp32 {e_f32:.2e} (vs fp64)")
+            assert e_gpu < max(1e-4, 3.0 * e_f32)
+        else:
+            assert float(grads[:768].abs().max()) == 0.0
+        # three optimisation steps against the fp32 oracle stepped the same way (train_classifier.py:104-116)
         ref.zero_grad(set_to_none=True)
         opt = torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=0.0001)
         for step in range(3):
-            lr_, _ = iho.train_step(ref, opt, data.cpu(), target)
+            lr_, _ = iho.train_step(ref, opt, xc, target)
             lg, _ = head.train_step(data, target.cuda())
-            assert abs(float(lg) - float(lr_)) < 5e-5 * max(1.0, abs(float(lr_))), (method, step)
+            assert abs(float(lg) - float(lr_)) < 1e-4 * max(1.0, abs(float(lr_))), (method, step)
         sd = head.state_dict()
-        assert rel_l2(sd["classifier.0.weight"], ref.classifier[0].weight.detach()) < 1e-5
-        assert rel_l2(sd["q"], ref.q.detach()) < 1e-5
+        assert rel_l2(sd["classifier.0.weight"], ref.classifier[0].weight.detach()) < 2e-5
+        assert rel_l2(sd["q"], ref.q.detach()) < 2e-5
 
 
 def test_errors():

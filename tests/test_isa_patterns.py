@@ -1,9 +1,18 @@
 """Build-time check on the generated gfx950 code (no GPU needed: hipcc cross-compiles).
 
-One instruction form is banned: a packed fp32 op (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) whose DESTINATION register pair
-is also a source that is read with an op_sel cross-selection.  hipcc produced it once, for the conv0 taps; that kernel gave
-sporadically wrong values whenever kernels of another stream shared its CUs (tools/race_probe.py).  The
-source no longer leads the compiler there; this test fails if a compiler or code change brings the form back anywhere."""
+One instruction encoding is banned from every kernel of the library: a packed fp32 op (v_pk_fma_f32 / v_pk_mul_f32 /
+v_pk_add_f32) with an `op_sel` bit set, i.e. whose LOW result lane sources the HIGH dword of a register pair.
+
+Why ("the concurrency miscompare"; reproducer and raw data under tools/conv0_race/): a conv0 kernel whose ten
+taps hipcc had compiled to `v_pk_fma_f32 ... op_sel:[0,1,0]` produced wrong even-channel outputs -- and only those -- whenever
+workgroups of the attention kernel were resident on the same CUs.  Every wrong element equals the correct sum minus exactly
+one tap, w[c][k] * x[k]; the taps that go missing are, frame parity by frame parity, precisely the taps whose instruction
+carries op_sel:[0,1,0] in that half of the loop body (k = 1, 5, 9 for the first frame of a pair, all odd k for the second);
+taps encoded with op_sel_hi only, the high lane and the odd channels are never affected.  The kernel is bit-exact alone and
+beside GEMM / LayerNorm kernels.  The low lane's multiplicand is read as zero, sporadically, under that co-residency: an
+undocumented hazard of this encoding as far as the ISA guide goes, so the library does not emit it -- the build uses
+-fno-slp-vectorize (the forms came from the compiler's SLP packing of scalar code) and this test fails if the encoding
+reappears anywhere."""
 import glob
 import os
 import re
@@ -14,42 +23,48 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "loco-asr_amd", "csrc")
-PAT = re.compile(r"^\s*(v_pk_\w+)\s+(v\[\d+:\d+\]),\s*([^,]+),\s*([^,]+)(?:,\s*([^ ]+))?(.*)$")
+PAT = re.compile(r"^\s*(v_pk_(?:fma|mul|add)_f32)\s+.*\bop_sel:\[([0-9,]+)\]")
+
+
+def makefile_flags():
+    """The flags the library is really built with (loco-asr_amd/csrc/Makefile), minus what -S does not take."""
+    text = open(os.path.join(CSRC, "Makefile")).read()
+    flags = re.search(r"^CXXFLAGS \?= (.*)$", text, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    return [f for f in flags if f not in ("-fPIC",)]
 
 
 def offenders(asm_path):
     bad = []
     for line in open(asm_path):
         m = PAT.match(line)
-        if not m:
-            continue
-        _, dst, s0, s1, s2, mods = m.groups()
-        sel = re.search(r"op_sel:\[([0-9,]+)\]", mods)
-        if not sel:
-            continue
-        bits = [int(x) for x in sel.group(1).split(",")]
-        for i, src in enumerate((s0.strip(), s1.strip(), (s2 or "").strip())):
-            if i < len(bits) and bits[i] == 1 and src == dst:
-                bad.append(line.strip())
+        if m and "1" in m.group(2):
+            bad.append(line.strip())
     return bad
 
 
 @pytest.mark.parametrize("src", sorted(os.path.basename(p) for p in glob.glob(os.path.join(CSRC, "*.hip"))))
-def test_no_in_place_packed_op_with_cross_selected_source(src, tmp_path):
+def test_no_packed_fp32_op_cross_selects_its_low_lane(src, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = str(tmp_path / (src + ".s"))
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out],
-                   check=True, capture_output=True)
+    subprocess.run([hipcc] + makefile_flags() + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True, capture_output=True)
     assert os.path.getsize(out) > 0
     bad = offenders(out)
     assert not bad, bad[:5]
 
 
+def test_the_build_disables_slp_packing():
+    assert "-fno-slp-vectorize" in makefile_flags()
+
+
 def test_the_detector_sees_the_form():
     import tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
-        fh.write("\tv_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]\n\tv_pk_fma_f32 v[36:37], v[36:37], v[34:35], s[2:3] op_sel_hi:[1,1,0]\n")
-    assert len(offenders(fh.name)) == 1
+        fh.write("\tv_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]\n"           # in place, cross-selected
+                 "\tv_pk_fma_f32 v[32:33], v[12:13], v[40:41], v[32:33] op_sel:[0,1,0]\n"          # not in place: just as wrong
+                 "\tv_pk_add_f32 v[18:19], v[18:19], v[18:19] op_sel:[0,1] op_sel_hi:[1,0]\n"      # the SLP vectoriser's horizontal add
+                 "\tv_pk_fma_f32 v[36:37], v[36:37], v[34:35], s[2:3] op_sel_hi:[1,1,0]\n"         # fine: high lane reading a low dword
+                 "\tv_pk_fma_f32 v[36:37], v[22:23], v[32:33], 0 op_sel_hi:[1,0,0]\n")             # fine
+    assert len(offenders(fh.name)) == 3
     os.unlink(fh.name)
