@@ -276,7 +276,8 @@ def main():
                 enc.set_profiling(False)
                 enc.precision = args.precision
                 result[key] = {"precision": alt, "value": round(B * T * 3 / ealt, 1), "unit": "frames/s",
-                               "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3)}
+                               "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3),
+                               "kernel_ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in st_alt.items()}}
         # The timed region above runs with per-kernel HIP events, which keep loco_forward on ONE stream.  Without them the
         # library's default for big batches is two half-batches on two streams (bit-identical output, loco_set_streams):
         # the same workload, un-profiled, for reference.  `value` stays the single-stream figure the roofline belongs to.

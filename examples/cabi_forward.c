@@ -68,14 +68,18 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMalloc((void**)&dout, nout * sizeof(float)));
     CHECK_HIP(hipMalloc(&ws, wsb));
     CHECK_HIP(hipMemcpyAsync(dwav, hwav, nin * sizeof(float), hipMemcpyHostToDevice, stream));
-    CHECK_LOCO(loco_forward(enc, dwav, NULL, B, L, dout, NULL, NULL, ws, wsb, stream));
+    /* loco_forward is the asynchronous entry point; loco_forward_checked = forward + stream synchronisation + the numeric-range
+     * status of precision mode f16x3, with a second pass on the exact-fp32 kernels should this input leave the fp16 planes' range */
+    int32_t used_fp32 = 0;
+    CHECK_LOCO(loco_forward_checked(enc, dwav, NULL, B, L, dout, NULL, NULL, ws, wsb, stream, &used_fp32));
     float* hout = (float*)malloc(nout * sizeof(float));
     CHECK_HIP(hipMemcpyAsync(hout, dout, nout * sizeof(float), hipMemcpyDeviceToHost, stream));
     CHECK_HIP(hipStreamSynchronize(stream));
     FILE* fo = fopen(argv[6], "wb");
     if (!fo || fwrite(hout, sizeof(float), nout, fo) != nout) { perror("out"); return 1; }
     fclose(fo);
-    printf("encoded %d x %ld samples -> [%d, %ld, 768], workspace %.1f MB\n", B, L, B, T, wsb / 1e6);
+    printf("encoded %d x %ld samples -> [%d, %ld, 768], workspace %.1f MB%s\n", B, L, B, T, wsb / 1e6,
+           used_fp32 ? " (re-run on the exact-fp32 kernels: activation range)" : "");
     loco_destroy(enc);
     return 0;
 }

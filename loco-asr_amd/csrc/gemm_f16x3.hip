@@ -266,7 +266,12 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
                                                  (lptr_t)(b_ + 2 * DPA + DPW + 16 * (NDW * wave + u) * SBK), 16, 0, 0);   \
         }                                                                                                                 \
     }
-#define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// The wait in front of each k-tile's barrier retires (a) this wave's DMA pieces of the NEXT tile (counted vmcnt: with the 3-stage
+// ring the newest tile stays in flight) and (b) -- lgkmcnt(0) -- every fragment read this wave has issued: the barrier is a raw
+// s_barrier, which waits for no counter, and the stage those reads come from is re-filled by other waves' DMA right behind it.
+// Without (b) hipcc keeps the last fragment read of a tile pending ACROSS the barrier (it did: the read sat between the last
+// MFMAs and the barrier, its lgkmcnt after it) -- ordered against the incoming DMA only by the DMA's longer latency.
+#define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
     f32x16 acc[2][2];   // 32x32x16 form
     f32x4 acc16[4][NJ];  // 16x16x32 form
@@ -331,15 +336,19 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         const _Float16* cb = lds + stage * DBUF;
         if (MF16) {
             h8 ah[4], al[4], wh[NJ], wl[NJ];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(cb + fa + 16 * i * SBK);
-                al[i] = *reinterpret_cast<const h8*>(cb + DPA + fa + 16 * i * SBK);
-            }
+            // fragment reads in the order the MFMAs below first need them: row group 0 and W sub-tile 0 (the first three MFMAs),
+            // then the other W sub-tiles, then row groups 1-3
+            ah[0] = *reinterpret_cast<const h8*>(cb + fa);
+            al[0] = *reinterpret_cast<const h8*>(cb + DPA + fa);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + (PERMW ? 4 : 16) * j * SBK);
                 if (TERMS == 3) wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + (PERMW ? 4 : 16) * j * SBK);
+            }
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(cb + fa + 16 * i * SBK);
+                al[i] = *reinterpret_cast<const h8*>(cb + DPA + fa + 16 * i * SBK);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         if (AHEAD == 2 && kt + 2 < nk) {
             DMA_WAIT_PENDING()
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         stage = stage + 1 == DSTAGES ? 0 : stage + 1;
@@ -548,11 +557,17 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     int tile = forced ? atoi(forced) : 0;
     if (tile == 0) {
         if (a.M >= 1024) {
-            // 256x256 / 16 waves is ~5 % ahead when it still yields >= 3 full rounds of 256 workgroups with N a multiple of 256
-            // (QKV, the conv layers); 256x128 / 8 waves otherwise
+            // Measured on MI355X (tools/gemm_split_bench.py --tiles=..., and bench.py with LOCO_GEMM_TILE_NARROW in the two-stream
+            // pipeline): 256x256 / 16 waves wins wherever N is a multiple of 256 and at least one full round of 256 workgroups exists (the
+            // halves of the two-stream schedule fill each other's tails) -- also
+            // for the N = 768 GEMMs (out-proj, FFN2, feature projection: -2.3 % of the whole step against 256x128); K <= 128 (the
+            // relative-position table: two k-tiles, then 128 KiB of stores per tile) is epilogue-bound and runs best as two small
+            // workgroups per CU (128x128 / 4 waves / 64 KiB: -6 %); 256x128 / 8 waves otherwise.  Two workgroups per CU did NOT pay for
+            // the projection GEMMs (128x128: -15...-20 %, 192x128 / 6 waves: -25 %): the L2 -> LDS traffic per FLOP doubles.
             const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
-            tile = (a.N % 256 == 0 && t256 >= 768) ? 1 : 2;
-            const char* narrow = getenv("LOCO_GEMM_TILE_NARROW");  // A/B knob for the N <= 768 GEMMs (out-proj, FFN2, projection, Qp)
+            if (a.K <= 128) tile = 4;
+            else tile = (a.N % 256 == 0 && t256 >= 256) ? 1 : 2;
+            const char* narrow = getenv("LOCO_GEMM_TILE_NARROW");  // A/B knob for the GEMMs that would take the 256x128 form
             if (tile == 2 && narrow) tile = atoi(narrow);
         } else {
             tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
