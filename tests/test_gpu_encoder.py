@@ -211,6 +211,33 @@ def test_hipgraph_replay_matches_eager_and_is_faster_for_one_utterance():
         enc.use_graphs = False
 
 
+def test_hipgraphs_are_dropped_when_the_sinusoid_table_or_the_weights_move():
+    """a captured graph holds the device pointer of the sinusoid table; a longer clip (> 4000 frames) makes the host
+    upload a bigger table and the library frees the old one, and re-loading weights re-finalises them at new addresses.  Both
+    must invalidate the captured graphs -- replaying the short clip's graph afterwards would read freed memory."""
+    m = la.SpeechT5ForSpeechToTextMI355X(2)
+    sd = la.synth.encoder_state_dict(0, 2)
+    pre, encsd = la.synth.split_state_dict(sd)
+    m.speecht5.encoder.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in encsd.items()})
+    m.speecht5.encoder.prenet.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
+    enc = m.to("cuda").speecht5.encoder
+    short = torch.from_numpy(la.synth.batch([16000])[0]).cuda()
+    long_ = torch.from_numpy(la.synth.batch([1_300_000], first_index=3)[0]).cuda()  # 4062 frames > the table's initial 4002 rows
+    eager_short = enc(input_values=short).last_hidden_state
+    enc.use_graphs = True
+    try:
+        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short) and len(enc._graphs) == 1
+        y_long = enc(input_values=long_).last_hidden_state  # grows the table: every captured graph is dropped first
+        assert tuple(y_long.shape) == (1, 4062, 768) and bool(torch.isfinite(y_long).all())
+        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short)  # re-captured against the new table
+        n_before = len(enc._graphs)
+        enc.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in encsd.items()})  # weights dirty -> re-finalise
+        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short)
+        assert len(enc._graphs) <= n_before
+    finally:
+        enc.use_graphs = False
+
+
 def test_two_stream_half_batches_are_bit_identical():
     """loco_set_streams(2): a large batch runs as two half-batches on two HIP streams (fork/join with events).  Clips are
     independent, so the result must equal the single-stream pass bit for bit -- ragged lengths, odd batch size, consecutive
