@@ -165,50 +165,91 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
 }
 
 constexpr int SBK = 32;
+#ifndef LOCO_GEMM_PIPE
+#define LOCO_GEMM_PIPE 1
+#endif
+
+// Diagnostic build only (-DLOCO_GEMM_STAMPS, tools/gemm_stamps.py): wave 0 of every workgroup records where its cycles go --
+// prologue / main loop / of which parked at the k-tile wait + barrier / epilogue / store drain -- into a buffer of its own.
+// No stamp exists in the shipped library.
+#ifdef LOCO_GEMM_STAMPS
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+#define GEMM_STAMP(t) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GEMM_STAMP(t) {}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
-// The GEMM kernel: 256x128x32 tile, 8 waves (4 x 2), ONE workgroup per CU, three-stage LDS ring filled by
-// global_load_lds_dwordx4 (no staging VGPRs, no ds_write): tile kt+2 is in flight while tile kt is consumed, retired
-// with a counted s_waitcnt vmcnt (never 0 inside the loop) and a raw s_barrier.  The DMA writes 1 KiB contiguously
-// per wave-instruction (16 rows x 64 B of one plane), so rows cannot be padded; bank conflicts are removed by an XOR
-// swizzle instead -- 16-byte piece c of row r is stored at position c ^ ((r>>2)&3), applied on the per-lane SOURCE
-// address and on the fragment reads alike (a 16-lane ds_read_b128 group then covers all 16 slots).
+// The GEMM kernel.  WM x WN waves, each computing 64 x 64 of a (64 WM) x (64 WN) tile as 4 x NJ accumulators of
+// v_mfma_f32_16x16x32_f16, ONE workgroup per CU unless WPS says otherwise.  A and W k-tiles (32 deep, hi and lo planes) stream
+// global -> LDS with global_load_lds_dwordx4 (no staging VGPRs, no ds_write) into TWO rings: AST slots for A, WST for W.  The A
+// operand is an activation that comes from HBM and is what a k-tile waits for (tools/gemm_stamps.py: with A served from L2 a
+// 256x256 k-tile takes 3 500 cycles, from HBM 3 800 - 4 100, the MFMAs alone 3 072), the weights are re-read by every row of
+// tiles and sit in L2 / the Infinity Cache: so the 160 KiB of LDS go to THREE A slots and TWO W slots for the 256x256 tile
+// (3 x 32 + 2 x 32 KiB) -- an A k-tile has two k-tiles of time to arrive, a W k-tile one.
+// The DMA writes 1 KiB contiguously per wave-instruction (16 rows x 64 B of one plane), so rows cannot be padded; bank
+// conflicts are removed by an XOR swizzle instead, applied on the per-lane SOURCE address and on the fragment reads alike.
+// Tiles are retired with counted s_waitcnt vmcnt(N) (the DMAs of the youngest A k-tile stay in flight) and a raw s_barrier.
+//
+// Tile forms: 4x4 = 256x256 / 16 waves (half the L2 -> LDS bytes per FLOP of 128x128); 3x4 = 192x256 / 12 waves (N = 768 on
+// 47 968 rows: 2.93 rounds of 256 workgroups instead of 2.2 paid as 3); 4x2 = 256x128 / 8 waves; 2x2 = 128x128 / 4 waves
+// (small M; two per CU for K <= 128); 8x1 with NJ = 3 = the grouped positional conv (N = 48 per group).
+// NJ: 16-column sub-tiles each wave computes.  WPS: waves per SIMD the register allocation must leave room for (0 = one
+// workgroup per CU).  TERMS: 3 = A_hi W_hi + A_lo W_hi + A_hi W_lo (fp32 class, the default); 2 = the W_lo term dropped, i.e.
+// the weights rounded to fp16 after their per-tensor power-of-two scale (opt-in precision mode "f16x2").
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) const h8* lds_h8p;
 
-// WM x WN waves of 64x64: 4x2 = 256x128 tile, 3-stage ring (144 KiB); 4x4 = 256x256 tile, 16 waves, 2 stages (128 KiB):
-// half the L2->LDS bytes per FLOP of the 128x128 tile; 2x2 = 128x128 tile, 3 stages (96 KiB) for small M.
-// MF16: issue v_mfma_f32_16x16x32_f16 (16 accumulators of 16x16 per wave) instead of 32x32x16 (4 of 32x32): same FLOPs,
-// LDS bytes and registers, but the chip sustains a higher clock on that shape when the matrix pipes are the power draw.
-// NJ: 16-column sub-tiles each wave actually computes (4, or 3 when N = 48: the positional conv's 48 outputs per group).
-// WPS: waves per SIMD the register allocation must leave room for (0 = one workgroup per CU: (WM * WN) / 4).  The two-per-CU
-// forms (192x128 / 6 waves and 128x128 / 4 waves, two-stage rings of 80 / 64 KiB) exist so that one workgroup's epilogue
-// (GELU + plane split on the VALU, 64-256 KiB of stores draining to HBM) runs under the OTHER workgroup's main loop.
-// TERMS: 3 = A_hi W_hi + A_lo W_hi + A_hi W_lo (fp32 class, the default);  2 = A_hi W_hi + A_lo W_hi, i.e. the weights rounded
-// to fp16 (after their per-tensor power-of-two scale: 11 significant bits at every level) and the activations kept hi + lo --
-// the opt-in precision mode "f16x2": no W_lo plane is streamed, a third fewer MFMAs, ~4e-4 relative L2 end to end.
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int DSTAGES, bool MF16, int NJ = 4, int WPS = 0, int TERMS = 3>
+// One LDS-DMA instruction in its scalar-base form, global_load_lds_dwordx4 voffset, sbase: written as asm because hipcc turns
+// "uniform base + zero-extended lane offset" back into one 64-bit VGPR address per plane (8 VGPRs and, at the 128-register budget of
+// the 16-wave form, a spill with a vmcnt(0) reload between the DMAs).  M0 = LDS byte address of the piece (wave-uniform); one wait
+// state between the SALU write of M0 and the DMA that reads it.  (M0 is a reserved register to hipcc, which rejects it as a clobber;
+// nothing else in this kernel uses it -- gfx9 DS instructions do not -- and tests/test_isa_patterns.py checks that.)
+#define DMA16(base_, voff_, ldsb_) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#define VMCNT_LGKM0(n_)                                                                                              \
+    {                                                                                                                \
+        static_assert((n_) >= 0 && (n_) <= 12, "vmcnt value not listed");                                            \
+        if ((n_) == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
+        else if ((n_) == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                              \
+        else if ((n_) == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                            \
+        else if ((n_) == 11) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");                            \
+        else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                                            \
+    }
+
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
                                                                                                   int tiles_n, int nblk) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
-    constexpr int DPA = DBM * SBK, DPW = DBN * SBK;  // halves per A / W plane
-    constexpr int DBUF = 2 * DPA + 2 * DPW;
-    constexpr int NDA = DBM / 16 / NW_;                                // 16-row DMA pieces per wave per A plane
-    constexpr int NDW = (DBN / 16 + NW_ - 1) / NW_;                    // ... per W plane (the last waves may have none)
+    constexpr int DPA = DBM * SBK, DPW = DBN * SBK;          // halves per A / W plane of one k-tile
+    constexpr int ABUF = 2 * DPA, WBUF = 2 * DPW;            // halves per ring slot (hi plane, lo plane)
+    constexpr int NDA = DBM / 16 / NW_;                      // 16-row DMA pieces per wave per A plane
+    constexpr int NDW = (DBN / 16 + NW_ - 1) / NW_;          // ... per W plane (the last waves may have none)
     constexpr int WPIECES = DBN / 16;
-    constexpr int NDMA = 2 * NDA + (TERMS == 3 ? 2 : 1) * NDW;        // DMA instructions per wave per k-tile
-    static_assert(NDA >= 1, "tile too small for the wave count");
-    static_assert(WPIECES % NW_ == 0 || DSTAGES == 2, "uneven W pieces need the 2-stage ring (vmcnt(0) waits only)");
-    static_assert(NJ == 4 || MF16, "NJ < 4 is implemented for the 16x16x32 path");
-    static_assert(TERMS == 3 || (TERMS == 2 && MF16), "the two-term form is implemented for the 16x16x32 path");
+    constexpr int NA = 2 * NDA, NWP = (TERMS == 3 ? 2 : 1) * NDW;  // DMA instructions per wave per k-tile: A side, W side
+    static_assert(NDA >= 1 && DBM % (16 * NW_) == 0, "tile too small for the wave count");
+    static_assert(AST >= WST && WST >= 2 && AST <= 3, "ring depths");
+    static_assert(WPIECES % NW_ == 0 || WST == 2, "uneven W pieces: no wait may leave W DMAs in flight");
+    static_assert(TERMS == 3 || TERMS == 2, "terms");
+    static_assert((size_t)(AST * ABUF + WST * WBUF) * 2 <= 160 * 1024, "LDS");
+    static_assert(2 * (DPA + 16 * 3 * SBK) < 65536 && 2 * (DPW + 16 * 3 * SBK) < 65536, "fragment offsets are ds_read immediates");
     // PERMW: the 16 W rows (output columns) fed to MFMA sub-tile j are {16 q + 4 j + e}, q, e = 0..3, instead of 16 j .. 16 j + 15.
     // The accumulator of lane quad q4 then holds columns 16 q4 + 4 j + e: over j = 0..3 one lane owns 16 CONSECUTIVE
     // columns of its row, which the epilogue writes as 16-byte pieces (split_gemm_store16).  Same FLOPs and LDS bytes;
     // only the fragment row of a lane and the W swizzle (piece ^ f((row >> 4) & 3), f = 0,2,3,1) change.  Used for fp16
     // plane outputs (-4..9 % time on FFN1 / conv layers); fp32 outputs keep the plain mapping, whose 16-byte pieces of
     // four neighbouring lanes already form 64-byte runs (the permuted form measured 4..15 % slower there).
-    constexpr bool PERMW = MF16 && NJ == 4 && (OUT_SPLIT || EPI == kEpiQkvScatter);
-    __shared__ __attribute__((aligned(16))) _Float16 lds[DSTAGES * DBUF];
+    constexpr bool PERMW = NJ == 4 && (OUT_SPLIT || EPI == kEpiQkvScatter);
+    __shared__ __attribute__((aligned(16))) _Float16 lds[AST * ABUF + WST * WBUF];  // A ring, then W ring
 
     int mt, nt, z;
     {
@@ -229,155 +270,266 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, h = lane >> 5;
+    const int r16 = lane & 15, q4 = lane >> 4;
 
-    // DMA sources: this wave fills NDA 16-row pieces of each A plane and NDW of each W plane.
-    // lane -> row lane/4, stored position lane%4, source piece pos ^ swz(row).
+    // DMA sources: this wave fills NDA 16-row pieces of each A plane and NDW of each W plane; lane -> row lane/4, stored
+    // position lane%4, source piece pos ^ swz(row).  Each source = a workgroup-uniform 64-bit base (plane pointer + tile
+    // origin + k offset: scalar registers) + a per-lane 32-bit byte offset inside the tile: one VGPR per piece.
     const int drow = lane >> 2, dpos = lane & 3;
-    long ga[NDA], gw[NDW];
+    unsigned va[NDA], vw[NDW];
 #pragma unroll
     for (int u = 0; u < NDA; ++u) {
         const int row = 16 * (NDA * wave + u) + drow;
         int ra = m0 + row;
-        ra = ra < p.M ? ra : p.M - 1;
-        ga[u] = aoff + (long)ra * p.lda + 8 * (dpos ^ (MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
+        ra = (ra < p.M ? ra : p.M - 1) - m0;
+        va[u] = 2u * (unsigned)(ra * (int)p.lda + 8 * (dpos ^ (3 * ((row >> 2) & 1))));
     }
 #pragma unroll
     for (int u = 0; u < NDW; ++u) {
         const int row = 16 * (NDW * wave + u) + drow;
         int rw = n0 + row;
-        rw = rw < p.N ? rw : p.N - 1;
-        gw[u] = woff + (long)rw * p.ldw + 8 * (dpos ^ (PERMW ? ((0x78 >> (2 * ((row >> 4) & 3))) & 3) : MF16 ? 3 * ((row >> 2) & 1) : ((row >> 2) & 3)));
+        rw = (rw < p.N ? rw : p.N - 1) - n0;
+        vw[u] = 2u * (unsigned)(rw * (int)p.ldw + 8 * (dpos ^ (PERMW ? ((0x78 >> (2 * ((row >> 4) & 3))) & 3) : 3 * ((row >> 2) & 1))));
     }
-#define DMA_ISSUE(kt, stage)                                                                                              \
-    {                                                                                                                     \
-        _Float16* b_ = lds + (stage) * DBUF;                                                                              \
-        _Pragma("unroll") for (int u = 0; u < NDA; ++u) {                                                                 \
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Ahi + ga[u] + (long)(kt) * SBK),                                  \
-                                             (lptr_t)(b_ + 16 * (NDA * wave + u) * SBK), 16, 0, 0);                       \
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Alo + ga[u] + (long)(kt) * SBK),                                  \
-                                             (lptr_t)(b_ + DPA + 16 * (NDA * wave + u) * SBK), 16, 0, 0);                 \
-        }                                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < NDW; ++u) if (WPIECES % NW_ == 0 || NDW * wave + u < WPIECES) {             \
-            __builtin_amdgcn_global_load_lds((gptr_t)(p.Whi + gw[u] + (long)(kt) * SBK),                                  \
-                                             (lptr_t)(b_ + 2 * DPA + 16 * (NDW * wave + u) * SBK), 16, 0, 0);             \
-            if (TERMS == 3)                                                                                               \
-                __builtin_amdgcn_global_load_lds((gptr_t)(p.Wlo + gw[u] + (long)(kt) * SBK),                              \
-                                                 (lptr_t)(b_ + 2 * DPA + DPW + 16 * (NDW * wave + u) * SBK), 16, 0, 0);   \
-        }                                                                                                                 \
+    const char* const bAh = reinterpret_cast<const char*>(p.Ahi + aoff + (long)m0 * p.lda);
+    const char* const bAl = reinterpret_cast<const char*>(p.Alo + aoff + (long)m0 * p.lda);
+    const char* const bWh = reinterpret_cast<const char*>(p.Whi + woff + (long)n0 * p.ldw);
+    const char* const bWl = reinterpret_cast<const char*>(p.Wlo + woff + (long)n0 * p.ldw);
+    const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)lds;  // LDS byte address of the ring
+    const int nk = p.K / SBK;
+    // k-tile t of the A / W operand into ring slot sl_; piece q_ of the wave's NA / NWP.  t is clamped to the last k-tile: the
+    // loop issues AST (WST) tiles ahead without a branch, the surplus DMAs re-fetch the last tile into a slot nobody reads again
+    // (all of them are retired by the vmcnt(0) in front of the epilogue: no DMA may land after the workgroup has given up its LDS).
+#define DMA_A(q_, t_, sl_)                                                                                                  \
+    {                                                                                                                       \
+        const int tt_ = (t_) < nk ? (t_) : nk - 1;                                                                          \
+        const unsigned d_ = lds0 + 2u * (unsigned)((sl_) * ABUF + ((q_) & 1) * DPA + 16 * (NDA * wave + ((q_) >> 1)) * SBK); \
+        DMA16((((q_) & 1) ? bAl : bAh) + (long)tt_ * (2 * SBK), va[(q_) >> 1], d_);                                         \
     }
-// The wait in front of each k-tile's barrier retires (a) this wave's DMA pieces of the NEXT tile (counted vmcnt: with the 3-stage
-// ring the newest tile stays in flight) and (b) -- lgkmcnt(0) -- every fragment read this wave has issued: the barrier is a raw
-// s_barrier, which waits for no counter, and the stage those reads come from is re-filled by other waves' DMA right behind it.
-// Without (b) hipcc keeps the last fragment read of a tile pending ACROSS the barrier (it did: the read sat between the last
-// MFMAs and the barrier, its lgkmcnt after it) -- ordered against the incoming DMA only by the DMA's longer latency.
-#define DMA_WAIT_PENDING() { if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else if (NDMA == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else if (NDMA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else if (NDMA == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+#define DMA_W(q_, t_, sl_)                                                                                                  \
+    {                                                                                                                       \
+        const int tt_ = (t_) < nk ? (t_) : nk - 1;                                                                          \
+        const int u_ = TERMS == 3 ? (q_) >> 1 : (q_);                                                                       \
+        const int pl_ = TERMS == 3 ? (q_) & 1 : 0;                                                                          \
+        if (WPIECES % NW_ == 0 || NDW * wave + u_ < WPIECES) {                                                              \
+            const unsigned d_ = lds0 + 2u * (unsigned)(AST * ABUF + (sl_) * WBUF + pl_ * DPW + 16 * (NDW * wave + u_) * SBK); \
+            DMA16((pl_ ? bWl : bWh) + (long)tt_ * (2 * SBK), vw[u_], d_);                                                   \
+        }                                                                                                                   \
+    }
 
-    f32x16 acc[2][2];   // 32x32x16 form
-    f32x4 acc16[4][NJ];  // 16x16x32 form
-    if (MF16) {
+    f32x4 acc16[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    [[maybe_unused]] unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, rt0 = 0, rt1 = 0;
+#ifdef LOCO_GEMM_STAMPS
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory");
+#endif
+    GEMM_STAMP(st0)
+
+    // Fragment reads: lane (r16, q4) reads row r16 of a 16-row sub-tile, 16-byte piece q4 (stored at q4 ^ swizzle(row)); one
+    // k-step per k-tile.  Kept as two LDS byte addresses per lane (A side, W side) that step from ring slot to ring slot by a
+    // scalar delta; every fragment of a slot is an immediate offset from them.
+    const int swz = 3 * ((r16 >> 2) & 1);
+    const int fa = (wm * 64 + r16) * SBK + 8 * (q4 ^ swz);
+    const int fw = PERMW ? (wn * 64 + 16 * (r16 >> 2) + (r16 & 3)) * SBK + 8 * (q4 ^ ((0x78 >> (2 * (r16 >> 2))) & 3))
+                         : (wn * 64 + r16) * SBK + 8 * (q4 ^ swz);
+    unsigned a_ad = lds0 + 2u * (unsigned)fa;
+    unsigned w_ad = lds0 + 2u * (unsigned)(AST * ABUF + fw);
+#define LDS_H8(ad_, halves_) (*(lds_h8p)(unsigned long)((ad_) + 2u * (unsigned)(halves_)))
+#define RD_A(i_, s_)                                       \
+    {                                                      \
+        ah[s_] = LDS_H8(a_ad, 16 * (i_) * SBK);            \
+        al[s_] = LDS_H8(a_ad, DPA + 16 * (i_) * SBK);      \
+    }
+#define RD_W(j_)                                                                         \
+    {                                                                                    \
+        wh[j_] = LDS_H8(w_ad, (PERMW ? 4 : 16) * (j_) * SBK);                            \
+        if (TERMS == 3) wl[j_] = LDS_H8(w_ad, DPW + (PERMW ? 4 : 16) * (j_) * SBK);      \
+    }
+#define MM(i_, s_, j_)                                                                                                    \
+    {                                                                                                                     \
+        if (TERMS == 3) acc16[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j_], ah[s_], acc16[i_][j_], 0, 0, 0);   \
+        acc16[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j_], al[s_], acc16[i_][j_], 0, 0, 0);                   \
+        acc16[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j_], ah[s_], acc16[i_][j_], 0, 0, 0);                   \
+    }
+#define SB() __builtin_amdgcn_sched_barrier(0);
+    // ring slots of the k-tile being multiplied, and the byte steps to the next slot
+    int sa = 0, sw = 0;
+#define A_STEP() (unsigned)(sa + 1 == AST ? -(AST - 1) * 2 * ABUF : 2 * ABUF)
+#define W_STEP() (unsigned)(sw + 1 == WST ? -(WST - 1) * 2 * WBUF : 2 * WBUF)
+
+#if LOCO_GEMM_PIPE
+    // ---- software-pipelined main loop: ONE barrier per k-tile, placed in the MIDDLE of the tile's MFMAs -----------------------
+    // A wave's fragments of tile kt are all in registers (or on their way) well before the tile's MFMAs end, so the barrier X_kt
+    // "every wave has read the slots of tile kt and every wave's DMA pieces of tile kt+1 have landed" can sit behind the reads of
+    // the last of the four row groups.  Behind it the slots of tile kt are re-filled (W tile kt + WST, A tile kt + AST) and -- no
+    // further barrier needed -- the fragments of tile kt+1 are read while the last row group's MFMAs run: A row group 0 into the
+    // free A slot, each W sub-tile into the registers of the sub-tile that has just been multiplied for the last time.  The
+    // matrix pipe has MFMAs queued on both sides of the barrier; a loop that stops at its barrier with empty registers pays
+    // DMA issue + LDS latency (~430 of ~3 500 cycles per k-tile) before the next tile's first MFMA.
+    // The DMA instructions are spread over the MFMA blocks behind the barrier: issued back to back they keep every wave of
+    // the SIMD out of the matrix pipe at the same time (an LDS-DMA instruction holds its wave for 60-180 cycles).
+    constexpr int JH = (NJ + 1) / 2;
+    constexpr int NBLK = 2 * NJ - JH;  // MFMA blocks (of TERMS MFMAs) behind the barrier
+    constexpr int NPC = NWP + NA;      // DMA pieces behind the barrier: W first (it must have landed one barrier earlier than A)
+    h8 ah[2], al[2], wh[NJ], wl[NJ];
+#pragma unroll
+    for (int t = 0; t < WST; ++t)
+#pragma unroll
+        for (int q = 0; q < NWP; ++q) DMA_W(q, t, t)
+#pragma unroll
+    for (int t = 0; t < AST; ++t)
+#pragma unroll
+        for (int q = 0; q < NA; ++q) DMA_A(q, t, t)
+    // Tile 0 and every W tile of the prologue have landed.  With three W slots the A pieces of tile 1 must have landed too: the
+    // in-loop wait leaves "the youngest NA + NWP" in flight, which in steady state are W and A of tile kt+2 but right after this
+    // prologue (all W first, then all A) would be the A pieces of tiles 1 AND 2.
+    VMCNT_LGKM0((WST == 3 ? AST - 2 : AST - 1) * NA)
+    __builtin_amdgcn_s_barrier();
+    GEMM_STAMP(st1)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) RD_W(j)
+    RD_A(0, 0)
+#define DMA_AFTER_BLOCK(b_)                                                       \
+    {                                                                             \
+        _Pragma("unroll") for (int q = 0; q < NPC; ++q)                           \
+            if (q * NBLK / NPC == (b_)) {                                         \
+                if (q < NWP) DMA_W(q < NWP ? q : 0, kt + WST, sw)                 \
+                else DMA_A(q < NWP ? 0 : q - NWP, kt + AST, sa)                   \
+            }                                                                     \
+        SB()                                                                      \
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned a_step = A_STEP(), w_step = W_STEP();
+        SB()
+        MM(0, 0, 0)  // first: only fragments read a sub-tile ago are waited for here
+        // (the empty asm pins the third MFMA here: instruction selection otherwise places it, a pure node whose only user is the
+        // loop-carried copy, at the END of the body -- across every sched_barrier -- and keeps the old A fragments alive for it)
+        asm volatile("" : "+v"(acc16[0][0]));
+        SB()
+        RD_A(1, 1)
+        SB()
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) MM(0, 0, j)
+        SB()
+        RD_A(2, 0)
+        SB()
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) MM(1, 1, j)
+        SB()
+        RD_A(3, 1)
+        SB()
+#pragma unroll
+        for (int j = 0; j < JH; ++j) MM(2, 0, j)
+        SB()
+        // X_kt: this wave's reads of tile kt's slots are complete (lgkmcnt) and its DMA pieces of tile kt+1 have landed (vmcnt: what
+        // may stay in flight is what was issued last behind X_kt-1 and is not needed before X_kt+1 -- the A pieces of tile kt+2
+        // when the A ring is deeper than the W ring, both sides' when both rings hold three)
+        VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = JH; j < NJ; ++j) {
+            MM(2, 0, j)
+            SB()
+            DMA_AFTER_BLOCK(j - JH)
+        }
+        a_ad += a_step;  // both sides now address tile kt+1's slots (after the last tile: stale bytes of a landed slot, never used)
+        w_ad += w_step;
+        RD_A(0, 0)
+        SB()
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            MM(3, 1, j)
+            SB()
+            DMA_AFTER_BLOCK(NJ - JH + j)
+            RD_W(j)
+            SB()
+        }
+        sa = sa + 1 == AST ? 0 : sa + 1;
+        sw = sw + 1 == WST ? 0 : sw + 1;
+        SB()
+    }
+#undef DMA_AFTER_BLOCK
+#else
+    // ---- plain main loop: fetch ahead, read all fragments, multiply, wait + barrier ------------------------------------------------
+    constexpr int LA = AST - 1, LW = WST - 1;  // k-tiles in flight beyond the one being multiplied
+#pragma unroll
+    for (int t = 0; t < LW; ++t)
+#pragma unroll
+        for (int q = 0; q < NWP; ++q) DMA_W(q, t, t)
+#pragma unroll
+    for (int t = 0; t < LA; ++t)
+#pragma unroll
+        for (int q = 0; q < NA; ++q) DMA_A(q, t, t)
+    VMCNT_LGKM0((LA - 1) * NA)
+    __builtin_amdgcn_s_barrier();
+    GEMM_STAMP(st1)
+    for (int kt = 0; kt < nk; ++kt) {
+        const unsigned a_step = A_STEP(), w_step = W_STEP();
+        {
+            const int swn = sw + LW >= WST ? sw + LW - WST : sw + LW, san = sa + LA >= AST ? sa + LA - AST : sa + LA;
+#pragma unroll
+            for (int q = 0; q < NWP; ++q) DMA_W(q, kt + LW, swn)
+#pragma unroll
+            for (int q = 0; q < NA; ++q) DMA_A(q, kt + LA, san)
+        }
+        h8 ah[4], al[4], wh[NJ], wl[NJ];
+        // fragment reads in the order the MFMAs below first need them
+        ah[0] = LDS_H8(a_ad, 0);
+        al[0] = LDS_H8(a_ad, DPA);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) RD_W(j)
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            ah[i] = LDS_H8(a_ad, 16 * i * SBK);
+            al[i] = LDS_H8(a_ad, DPA + 16 * i * SBK);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    }
-
-    const int nk = p.K / SBK;
-    constexpr int AHEAD = DSTAGES - 1;  // tiles in flight beyond the one being consumed
-    DMA_ISSUE(0, 0)
-    if (AHEAD == 2 && nk > 1) {
-        DMA_ISSUE(1, 1)
-        DMA_WAIT_PENDING()
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-
-    // 32x32x16: lane (r, h) reads row r of a 32-row sub-tile, piece 2 ks + h;  16x16x32: lane (r16, q) reads row r16 of a
-    // 16-row sub-tile, piece q (one k-step per k-tile).  The stored position is piece ^ swizzle(row).
-    const int r16 = lane & 15, q4 = lane >> 4;
-    const int swz = MF16 ? 3 * ((r16 >> 2) & 1) : ((r >> 2) & 3);
-    const int fa = MF16 ? (wm * 64 + r16) * SBK + 8 * (q4 ^ swz) : (wm * 64 + r) * SBK;
-    const int fw = PERMW  ? (wn * 64 + 16 * (r16 >> 2) + (r16 & 3)) * SBK + 8 * (q4 ^ ((0x78 >> (2 * (r16 >> 2))) & 3))
-                   : MF16 ? (wn * 64 + r16) * SBK + 8 * (q4 ^ swz)
-                          : (wn * 64 + r) * SBK;
-#define DMA_FRAGS(b_, ks, F)                                                                          \
-    {                                                                                                 \
-        const int po_ = 8 * ((2 * (ks) + h) ^ swz);                                                   \
-        F[0] = *reinterpret_cast<const h8*>((b_) + fa + po_);                                         \
-        F[1] = *reinterpret_cast<const h8*>((b_) + fa + 32 * SBK + po_);                              \
-        F[2] = *reinterpret_cast<const h8*>((b_) + DPA + fa + po_);                                   \
-        F[3] = *reinterpret_cast<const h8*>((b_) + DPA + fa + 32 * SBK + po_);                        \
-        F[4] = *reinterpret_cast<const h8*>((b_) + 2 * DPA + fw + po_);                               \
-        F[5] = *reinterpret_cast<const h8*>((b_) + 2 * DPA + fw + 32 * SBK + po_);                    \
-        F[6] = *reinterpret_cast<const h8*>((b_) + 2 * DPA + DPW + fw + po_);                         \
-        F[7] = *reinterpret_cast<const h8*>((b_) + 2 * DPA + DPW + fw + 32 * SBK + po_);              \
-    }
-#define DMA_MFMA(F)                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[6 + j], F[i], acc[i][j], 0, 0, 0);              \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[2 + i], acc[i][j], 0, 0, 0);          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[4 + j], F[i], acc[i][j], 0, 0, 0);              \
-        }
-
-    int stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        int nstage = stage + AHEAD;
-        nstage = nstage >= DSTAGES ? nstage - DSTAGES : nstage;
-        if (kt + AHEAD < nk) DMA_ISSUE(kt + AHEAD, nstage)
-        const _Float16* cb = lds + stage * DBUF;
-        if (MF16) {
-            h8 ah[4], al[4], wh[NJ], wl[NJ];
-            // fragment reads in the order the MFMAs below first need them: row group 0 and W sub-tile 0 (the first three MFMAs),
-            // then the other W sub-tiles, then row groups 1-3
-            ah[0] = *reinterpret_cast<const h8*>(cb + fa);
-            al[0] = *reinterpret_cast<const h8*>(cb + DPA + fa);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                wh[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + fw + (PERMW ? 4 : 16) * j * SBK);
-                if (TERMS == 3) wl[j] = *reinterpret_cast<const h8*>(cb + 2 * DPA + DPW + fw + (PERMW ? 4 : 16) * j * SBK);
-            }
-#pragma unroll
-            for (int i = 1; i < 4; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(cb + fa + 16 * i * SBK);
-                al[i] = *reinterpret_cast<const h8*>(cb + DPA + fa + 16 * i * SBK);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    if (TERMS == 3) acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al[i], acc16[i][j], 0, 0, 0);
-                    acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc16[i][j], 0, 0, 0);
-                }
-        } else {
-            h8 fx[8], fy[8];
-            DMA_FRAGS(cb, 0, fx)
-            DMA_FRAGS(cb, 1, fy)
-            DMA_MFMA(fx)
-            DMA_MFMA(fy)
-        }
-        // retire the next tile; with a 3-stage ring the newest tile's DMAs stay in flight across the barrier
-        if (AHEAD == 2 && kt + 2 < nk) {
-            DMA_WAIT_PENDING()
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
+            for (int j = 0; j < NJ; ++j) MM(i, i, j)
+        // retire tile kt+1: every fragment read this wave has issued (the slots are re-filled behind the barrier) and its DMA
+        // pieces of the next tile; the youngest A tile (both sides' with two three-slot rings) stays in flight
+        VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
         __builtin_amdgcn_s_barrier();
-        stage = stage + 1 == DSTAGES ? 0 : stage + 1;
+        a_ad += a_step;
+        w_ad += w_step;
+        sa = sa + 1 == AST ? 0 : sa + 1;
+        sw = sw + 1 == WST ? 0 : sw + 1;
     }
-#undef DMA_MFMA
-#undef DMA_FRAGS
-#undef DMA_ISSUE
-#undef DMA_WAIT_PENDING
+#endif  // LOCO_GEMM_PIPE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last k-tiles: none may land after this workgroup's LDS is given away
+#undef A_STEP
+#undef W_STEP
+#undef SB
+#undef MM
+#undef RD_W
+#undef RD_A
+#undef LDS_H8
+#undef DMA_W
+#undef DMA_A
+    GEMM_STAMP(st2)
+#ifdef LOCO_GEMM_STAMPS
+#define GEMM_STAMPS_OUT()                                                                                                   \
+    {                                                                                                                       \
+        GEMM_STAMP(st3)                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                    \
+        GEMM_STAMP(st4)                                                                                                     \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");                                   \
+        if (g_gemm_stamps && tid == 0) {                                                                                    \
+            unsigned hw;                                                                                                    \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));                                               \
+            unsigned long long* o_ = g_gemm_stamps + 8l * blockIdx.x;                                                       \
+            o_[0] = st1 - st0; o_[1] = st2 - st1; o_[2] = 0; o_[3] = st3 - st2; o_[4] = st4 - st3; o_[5] = rt0; o_[6] = rt1; \
+            o_[7] = hw;                                                                                                     \
+        }                                                                                                                   \
+    }
+#else
+#define GEMM_STAMPS_OUT() {}
+#endif
 
     // Epilogue.  The accumulators hold 2^k times the product (the weight planes are pre-scaled, GemmSplitArgs::out_scale):
     // one exact multiply restores it.  amax = max|x| of what this lane writes into fp16 planes (range tracking).
@@ -402,48 +554,30 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
             }
         }
         range_commit(p.range_slot, amax, seen);
+        GEMM_STAMPS_OUT()
         return;
     }
-    if (MF16) {
-        // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
+    // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + 16 * i + r16;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * 64 + 16 * j + 4 * q4;
-                if (n < p.N) {
-                    f32x4 v = acc16[i][j] * osc;
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
-                }
-            }
-        }
-        if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + 16 * i + r16;
         if (m >= p.M) continue;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-                if (n < p.N) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * osc;
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax);
-                }
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * q4;
+            if (n < p.N) {
+                f32x4 v = acc16[i][j] * osc;
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
+                split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
             }
         }
     }
     if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
+    GEMM_STAMPS_OUT()
 }
+#undef GEMM_STAMPS_OUT
+#undef VMCNT_LGKM0
+#undef DMA16
 
 // Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns.
 template <int EPI, bool OUT_SPLIT>
@@ -465,8 +599,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int
     if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);  // every lane of the wave gets here
 }
 
-// One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, DST ring stages, WPS as in the kernel template.
-template <int WM, int WN, int DST, int WPS, int TERMS = 3>
+// One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, AST / WST ring slots, WPS as in the kernel template.
+template <int WM, int WN, int AST, int WST, int WPS, int TERMS = 3>
 static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     constexpr int bm = 64 * WM, bn = 64 * WN;
     const int tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn;
@@ -474,9 +608,9 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     const bool sp = a.Chi != nullptr;
 #define TILE_LAUNCH(EPI)                                                                                                              \
-    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, DST, true, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, \
+    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, \
                                s, a, tm, tn, (int)nb);                                                                                \
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, DST, true, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0,  \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0,  \
                             s, a, tm, tn, (int)nb);
     switch (a.epilogue) {
         case kEpiNone: TILE_LAUNCH(kEpiNone) break;
@@ -506,10 +640,10 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         const long nb = (long)tm * a.nb1 * a.nb2;
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
         if (a.terms == 2)
-            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
+            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
                                (int)nb);
         else
-            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, true, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
+            hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
                                (int)nb);
         return hipGetLastError();
     }
@@ -567,28 +701,43 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
             if (a.K <= 128) tile = 4;
             else tile = (a.N % 256 == 0 && t256 >= 256) ? 1 : 2;
+            if (tile == 1 && !a.co_scheduled && !getenv("LOCO_GEMM_NO192")) {
+                // Whole rounds of 256 workgroups are what a launch costs: 47 968 x 768 is 564 tiles of 256x256 = 2.2 rounds, paid as 3,
+                // but 750 tiles of 192x256 (12 waves, 112 KiB ring) = 2.93 rounds of a tile 3/4 the size: out-proj -15 %, FFN2 -12 %.
+                // Per FLOP the 192-row form is ~10 % behind (more L2 -> LDS bytes, 3 waves per SIMD), so it is chosen only when its
+                // rounds x rows, so weighted, come out lower -- and not under the two half-batch schedule, where the other stream's
+                // workgroups fill the last round anyway (measured: 256x256 +1.3 % there).
+                const long t192 = (long)((a.M + 191) / 192) * (a.N / 256) * a.nb1 * a.nb2;
+                const long c256 = ((t256 + 255) / 256) * 256 * 10, c192 = ((t192 + 255) / 256) * 192 * 11;
+                if (c192 < c256) tile = 6;
+            }
             const char* narrow = getenv("LOCO_GEMM_TILE_NARROW");  // A/B knob for the GEMMs that would take the 256x128 form
             if (tile == 2 && narrow) tile = atoi(narrow);
         } else {
             tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
         }
     }
+    // ring depths: 256x256 -> three A slots + two W slots = 160 KiB; 192x256 -> 3 + 2 = 136 KiB; 256x128 and the one-per-CU
+    // 128x128 -> 3 + 3; the two-per-CU forms 2 + 2
     if (a.terms == 2) {  // precision mode "f16x2": the weights' lo plane is neither streamed nor multiplied
         switch (tile) {
-            case 1: return launch_tile<4, 4, 2, 0, 2>(a, s);
-            case 2: return launch_tile<4, 2, 3, 0, 2>(a, s);
-            case 4: return launch_tile<2, 2, 2, 2, 2>(a, s);
+            case 1: return launch_tile<4, 4, 3, 2, 0, 2>(a, s);
+            case 2: return launch_tile<4, 2, 3, 3, 0, 2>(a, s);
+            case 4: return launch_tile<2, 2, 2, 2, 2, 2>(a, s);
+            case 6: return launch_tile<3, 4, 3, 2, 0, 2>(a, s);
             case 3:
-            case 5: return launch_tile<2, 2, 3, 0, 2>(a, s);
+            case 5: return launch_tile<2, 2, 3, 3, 0, 2>(a, s);
             default: return hipErrorInvalidValue;
         }
     }
     switch (tile) {
-        case 1: return launch_tile<4, 4, 2, 0>(a, s);
-        case 2: return launch_tile<4, 2, 3, 0>(a, s);
-        case 3: return launch_tile<3, 2, 2, 3>(a, s);
-        case 4: return launch_tile<2, 2, 2, 2>(a, s);
-        case 5: return launch_tile<2, 2, 3, 0>(a, s);
+        case 1: return launch_tile<4, 4, 3, 2, 0>(a, s);
+        case 2: return launch_tile<4, 2, 3, 3, 0>(a, s);
+        case 3: return launch_tile<3, 2, 2, 2, 3>(a, s);
+        case 4: return launch_tile<2, 2, 2, 2, 2>(a, s);
+        case 5: return launch_tile<2, 2, 3, 3, 0>(a, s);
+        case 6: return launch_tile<3, 4, 3, 2, 0>(a, s);
+        case 7: return launch_tile<4, 4, 2, 2, 0>(a, s);  // A/B: the 256x256 form with two slots per side (128 KiB)
         default: return hipErrorInvalidValue;
     }
 }
@@ -670,3 +819,9 @@ hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStrea
 }
 
 }  // namespace loco
+
+#ifdef LOCO_GEMM_STAMPS
+extern "C" int loco_debug_set_gemm_stamps(void* buf) {  // diagnostic build only: 8 x u64 per workgroup of the next launches
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(loco::g_gemm_stamps), &buf, sizeof(buf));
+}
+#endif

@@ -115,6 +115,7 @@ struct loco_encoder {
     // concurrency: a batch may run as two half-batches on two streams (loco_set_streams)
     int streams = 2;
     hipStream_t side = nullptr;
+    bool dual_active = false;  // inside the two half-batch schedule (GemmSplitArgs::co_scheduled)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // range tracking of the fp16-plane activations (loco_kernels.h, range_commit): one status word x 8 shards per stage
     float* range_dev = nullptr;   // [kRangeMaxStages][kRangeShards], zeroed at the start of every forward
@@ -313,6 +314,7 @@ int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _F
     a.Rlo = Rlo;
     a.out_scale = Wt.inv_scale;
     a.range_slot = range_slot;
+    a.co_scheduled = e->dual_active;
     a.terms = (e->precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
@@ -1110,12 +1112,14 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
     // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
+    e->dual_active = true;
     rc = forward_one(e, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
     int rc1 = LOCO_OK;
     std::string first_error;
     if (rc) first_error = g_err;
     else rc1 = forward_one(e, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
                            out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
+    e->dual_active = false;
     if (!rc && rc1) first_error = g_err;
     const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves
     const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, e->ev_join, 0) : j1;

@@ -77,6 +77,9 @@ struct GemmSplitArgs {
     // out_scale = 2^-k before bias / activation -- exact, a power of two.
     float out_scale = 1.0f;
     int terms = 3;  // 3: A_hi W_hi + A_lo W_hi + A_hi W_lo;  2: the W_lo term dropped (precision mode "f16x2")
+    // true while another stream of the same forward is launching kernels of its own (the two half-batch schedule): a partly filled
+    // last round is then filled by that stream's workgroups, and the tile choice stops paying for whole rounds
+    bool co_scheduled = false;
     // Range tracking: where the output is written as fp16 hi/lo planes, max|x| of what was written is folded into
     // range_slot[0..7] (see range_commit); null = not tracked.
     float* range_slot = nullptr;

@@ -330,6 +330,44 @@ def test_gemm_f16x3_large_tiles(epi, out_split):
     assert rel_l2(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("K", [32, 64, 96, 128, 160, 256, 1024])
+def test_gemm_f16x3_every_tile_form_agrees_bit_for_bit(K):
+    """The ring protocol of the LDS-DMA kernel (which slot a DMA may overwrite, which DMAs a counted vmcnt may leave in flight) is
+    where a wrong count reads stale or half-landed bytes -- sporadically, and only in SOME tile form / ring depth.  Every form
+    accumulates a given output element in the same order (k-tile by k-tile, three MFMAs per k-tile), so all forms must agree BIT
+    FOR BIT, on every repeat, for k-loops shorter than, equal to and longer than the rings (K = 32 ... 1024 = 1 ... 32 k-tiles);
+    one form is also checked against fp64.  (A prologue that waited for too few A pieces when both rings had three slots passed
+    every tolerance test of this file by timing luck and failed only a determinism check of the whole encoder.)"""
+    import os
+    M, N = 30011, 768
+    A = hu("g5.a", (M, K), 2.0)
+    W = hu("g5.w", (N, K), 2.0 / math.sqrt(K))
+    b = hu("g5.b", (N,))
+    ahi, alo = split16(A)
+    whi, wlo = split16(W)
+    bd = dev(b)
+    outs = {}
+    try:
+        for tile in (2, 1, 3, 4, 5, 6, 7):
+            os.environ["LOCO_GEMM_TILE"] = str(tile)
+            for rep in range(3):
+                chi = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+                clo = torch.zeros_like(chi)
+                check(lib().loco_op_gemm_f16x3(ptr(ahi), ptr(alo), K, ptr(whi), ptr(wlo), K, ptr(bd), None, N, None, ptr(chi), ptr(clo), N, M, N, K,
+                                               1, 1, 1, 0, 0, 0, 0, stream()))
+                torch.cuda.synchronize()
+                if not outs:
+                    ref = A.double() @ W.double().t() + b.double()
+                    ref = 0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))
+                    assert rel_l2(chi.float() + clo.float(), ref) < 5e-6
+                    outs["hi"], outs["lo"] = chi, clo
+                else:
+                    nbad = int((chi.view(torch.int16) != outs["hi"].view(torch.int16)).sum()) + int((clo.view(torch.int16) != outs["lo"].view(torch.int16)).sum())
+                    assert nbad == 0, (tile, rep, nbad)
+    finally:
+        os.environ.pop("LOCO_GEMM_TILE", None)
+
+
 def test_gemm_f16x3_batched_strided_conv_large():
     """conv layer as a batched split GEMM on the big-tile kernel: 9 clips x 12 001 frames, k=3, stride 2."""
     Cc, k, s_, Tin, B = 512, 3, 2, 24003, 9

@@ -68,3 +68,23 @@ def test_the_detector_sees_the_form():
                  "\tv_pk_fma_f32 v[36:37], v[22:23], v[32:33], 0 op_sel_hi:[1,0,0]\n")             # fine
     assert len(offenders(fh.name)) == 3
     os.unlink(fh.name)
+
+
+def test_m0_is_written_only_for_the_lds_dma_in_the_gemm(tmp_path):
+    """gemm_f16x3.hip issues its LDS-DMA as inline asm that writes M0 (the piece's LDS address) without declaring the clobber --
+    hipcc treats M0 as reserved and rejects it in a clobber list.  That is sound only while the compiler itself never keeps a value
+    in M0 in that translation unit: every instruction that names m0 must be the asm's own `s_mov_b32 m0, sN`, followed (after its
+    one wait state) by the global_load_lds_dwordx4 that consumes it."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "gemm_f16x3.s")
+    subprocess.run([hipcc] + makefile_flags() + ["-S", "--cuda-device-only", os.path.join(CSRC, "gemm_f16x3.hip"), "-o", out], check=True,
+                   capture_output=True)
+    lines = [ln.split(";")[0].strip() for ln in open(out)]
+    lines = [ln for ln in lines if ln and not ln.startswith(".")]
+    uses = [i for i, ln in enumerate(lines) if re.search(r"\bm0\b", ln)]
+    assert len(uses) > 100  # the DMAs are there
+    for i in uses:
+        assert re.fullmatch(r"s_mov_b32 m0, s\d+", lines[i]), lines[i]
+        assert lines[i + 1] == "s_nop 0" and lines[i + 2].startswith("global_load_lds_dwordx4 v"), lines[i:i + 3]
