@@ -373,7 +373,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     // The DMA instructions are spread over the MFMA blocks behind the barrier: issued back to back they keep every wave of
     // the SIMD out of the matrix pipe at the same time (an LDS-DMA instruction holds its wave for 60-180 cycles).
     constexpr int JH = (NJ + 1) / 2;
-    constexpr int NBLK = 2 * NJ - JH;  // MFMA blocks (of TERMS MFMAs) behind the barrier
+    constexpr int NG = (NJ + 1) / 2;   // pairs of W sub-tiles
+    constexpr int NBLK = 1 + NG;       // MFMA blocks behind the barrier: the rest of row group 2, then row group 3 pair by pair
     constexpr int NPC = NWP + NA;      // DMA pieces behind the barrier: W first (it must have landed one barrier earlier than A)
     h8 ah[2], al[2], wh[NJ], wl[NJ];
 #pragma unroll
@@ -404,16 +405,20 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     }
     for (int kt = 0; kt < nk; ++kt) {
         const unsigned a_step = A_STEP(), w_step = W_STEP();
+        // MFMA blocks between two pins hold two W sub-tiles (two independent accumulator chains of TERMS MFMAs each, which hipcc
+        // interleaves): three dependent MFMAs back to back leave the matrix pipe to the other waves of the SIMD for 2 x 16 cycles
         SB()
-        MM(0, 0, 0)  // first: only fragments read a sub-tile ago are waited for here
-        // (the empty asm pins the third MFMA here: instruction selection otherwise places it, a pure node whose only user is the
-        // loop-carried copy, at the END of the body -- across every sched_barrier -- and keeps the old A fragments alive for it)
-        asm volatile("" : "+v"(acc16[0][0]));
+        MM(0, 0, 0)  // first: only fragments read a block ago are waited for here
+        if (NJ > 1) MM(0, 0, 1)
+        // (the empty asm pins these MFMAs here: instruction selection otherwise places the last one of a chain, a pure node whose
+        // only user is the loop-carried copy, at the END of the body -- across every sched_barrier -- and keeps the old A
+        // fragments alive for it)
+        asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][NJ > 1 ? 1 : 0]));
         SB()
         RD_A(1, 1)
         SB()
 #pragma unroll
-        for (int j = 1; j < NJ; ++j) MM(0, 0, j)
+        for (int j = 2; j < NJ; ++j) MM(0, 0, j)
         SB()
         RD_A(2, 0)
         SB()
@@ -431,21 +436,21 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int j = JH; j < NJ; ++j) {
-            MM(2, 0, j)
-            SB()
-            DMA_AFTER_BLOCK(j - JH)
-        }
+        for (int j = JH; j < NJ; ++j) MM(2, 0, j)
+        SB()
+        DMA_AFTER_BLOCK(0)
         a_ad += a_step;  // both sides now address tile kt+1's slots (after the last tile: stale bytes of a landed slot, never used)
         w_ad += w_step;
         RD_A(0, 0)
         SB()
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            MM(3, 1, j)
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) MM(3, 1, j)
             SB()
-            DMA_AFTER_BLOCK(NJ - JH + j)
-            RD_W(j)
+            DMA_AFTER_BLOCK(1 + g)
+#pragma unroll
+            for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) RD_W(j)
             SB()
         }
         sa = sa + 1 == AST ? 0 : sa + 1;
