@@ -165,9 +165,6 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
 }
 
 constexpr int SBK = 32;
-#ifndef LOCO_GEMM_PIPE
-#define LOCO_GEMM_PIPE 1
-#endif
 
 // Diagnostic build only (-DLOCO_GEMM_STAMPS, tools/gemm_stamps.py): wave 0 of every workgroup records where its cycles go --
 // prologue / main loop / of which parked at the k-tile wait + barrier / epilogue / store drain -- into a buffer of its own.
@@ -228,7 +225,7 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 
 template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
-                                                                                                  int tiles_n, int nblk) {
+                                                                                                  int tiles_n, int nblk, int wg_step) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
     constexpr int DPA = DBM * SBK, DPW = DBN * SBK;          // halves per A / W plane of one k-tile
     constexpr int ABUF = 2 * DPA, WBUF = 2 * DPW;            // halves per ring slot (hi plane, lo plane)
@@ -251,77 +248,92 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     constexpr bool PERMW = NJ == 4 && (OUT_SPLIT || EPI == kEpiQkvScatter);
     __shared__ __attribute__((aligned(16))) _Float16 lds[AST * ABUF + WST * WBUF];  // A ring, then W ring
 
-    int mt, nt, z;
-    {
-        const int q = nblk >> 3, rr = nblk & 7;
-        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
-        const int t = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + i;
-        nt = t % tiles_n;
-        const int rest = t / tiles_n;
-        mt = rest % tiles_m;
-        z = rest / tiles_m;
-    }
-    const int z1 = z / p.nb2, z2 = z % p.nb2;
-    const long aoff = z1 * p.sA1 + z2 * p.sA2;
-    const long coff = z1 * p.sC1 + z2 * p.sC2;
-    const long woff = z2 * p.sW2;
-    const int m0 = mt * DBM, n0 = nt * DBN;
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, q4 = lane >> 4;
-
-    // DMA sources: this wave fills NDA 16-row pieces of each A plane and NDW of each W plane; lane -> row lane/4, stored
-    // position lane%4, source piece pos ^ swz(row).  Each source = a workgroup-uniform 64-bit base (plane pointer + tile
-    // origin + k offset: scalar registers) + a per-lane 32-bit byte offset inside the tile: one VGPR per piece.
     const int drow = lane >> 2, dpos = lane & 3;
-    unsigned va[NDA], vw[NDW];
-#pragma unroll
-    for (int u = 0; u < NDA; ++u) {
-        const int row = 16 * (NDA * wave + u) + drow;
-        int ra = m0 + row;
-        ra = (ra < p.M ? ra : p.M - 1) - m0;
-        va[u] = 2u * (unsigned)(ra * (int)p.lda + 8 * (dpos ^ (3 * ((row >> 2) & 1))));
-    }
-#pragma unroll
-    for (int u = 0; u < NDW; ++u) {
-        const int row = 16 * (NDW * wave + u) + drow;
-        int rw = n0 + row;
-        rw = (rw < p.N ? rw : p.N - 1) - n0;
-        vw[u] = 2u * (unsigned)(rw * (int)p.ldw + 8 * (dpos ^ (PERMW ? ((0x78 >> (2 * ((row >> 4) & 3))) & 3) : 3 * ((row >> 2) & 1))));
-    }
-    const char* const bAh = reinterpret_cast<const char*>(p.Ahi + aoff + (long)m0 * p.lda);
-    const char* const bAl = reinterpret_cast<const char*>(p.Alo + aoff + (long)m0 * p.lda);
-    const char* const bWh = reinterpret_cast<const char*>(p.Whi + woff + (long)n0 * p.ldw);
-    const char* const bWl = reinterpret_cast<const char*>(p.Wlo + woff + (long)n0 * p.ldw);
-    const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)lds;  // LDS byte address of the ring
+    const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)lds;  // LDS byte address of the rings
     const int nk = p.K / SBK;
-    // k-tile t of the A / W operand into ring slot sl_; piece q_ of the wave's NA / NWP.  t is clamped to the last k-tile: the
-    // loop issues AST (WST) tiles ahead without a branch, the surplus DMAs re-fetch the last tile into a slot nobody reads again
-    // (all of them are retired by the vmcnt(0) in front of the epilogue: no DMA may land after the workgroup has given up its LDS).
-#define DMA_A(q_, t_, sl_)                                                                                                  \
+
+    // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2); each XCD gets a contiguous
+    // run of output tiles, column tile fastest, so that the tiles in flight on one L2 share their A rows.  PERSISTENT form
+    // (wg_step > 0: the grid is one workgroup per CU slot): a workgroup walks its XCD's run with stride wg_step, and the DMA
+    // stream simply runs on into the next output tile -- its first k-tiles are fetched while this tile's last ones are multiplied
+    // and its epilogue runs, so no tile but the first waits for a cold prologue (6-9 % of a tile's life at K = 768 / 1536).
+    const int xcd = blockIdx.x & 7;
+    int tile_i = blockIdx.x >> 3;  // index inside the XCD's run
+    int run_start, run_len;
+    {
+        const int q = nblk >> 3, rr = nblk & 7;
+        run_start = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+        run_len = q + (xcd < rr ? 1 : 0);
+    }
+    // DMA sources of an output tile: this wave fills NDA 16-row pieces of each A plane and NDW of each W plane; lane -> row
+    // lane/4, stored position lane%4, source piece pos ^ swz(row).  Each source = a workgroup-uniform 64-bit base (plane pointer
+    // + tile origin + k offset: scalar registers) + a per-lane 32-bit byte offset inside the tile: one VGPR per piece.
+    struct Tile {
+        const char *bAh, *bAl, *bWh, *bWl;
+        unsigned va[NDA], vw[NDW];
+        int m0, n0, z1, z2;
+        long coff;
+    };
+    auto decode = [&](int i, Tile& t_) {
+        const int t = run_start + i;
+        const int nt = t % tiles_n;
+        const int rest = t / tiles_n;
+        const int mt = rest % tiles_m;
+        const int z = rest / tiles_m;
+        t_.z1 = z / p.nb2;
+        t_.z2 = z % p.nb2;
+        const long aoff = t_.z1 * p.sA1 + t_.z2 * p.sA2;
+        const long woff = t_.z2 * p.sW2;
+        t_.coff = t_.z1 * p.sC1 + t_.z2 * p.sC2;
+        t_.m0 = mt * DBM;
+        t_.n0 = nt * DBN;
+#pragma unroll
+        for (int u = 0; u < NDA; ++u) {
+            const int row = 16 * (NDA * wave + u) + drow;
+            int ra = t_.m0 + row;
+            ra = (ra < p.M ? ra : p.M - 1) - t_.m0;
+            t_.va[u] = 2u * (unsigned)(ra * (int)p.lda + 8 * (dpos ^ (3 * ((row >> 2) & 1))));
+        }
+#pragma unroll
+        for (int u = 0; u < NDW; ++u) {
+            const int row = 16 * (NDW * wave + u) + drow;
+            int rw = t_.n0 + row;
+            rw = (rw < p.N ? rw : p.N - 1) - t_.n0;
+            t_.vw[u] = 2u * (unsigned)(rw * (int)p.ldw + 8 * (dpos ^ (PERMW ? ((0x78 >> (2 * ((row >> 4) & 3))) & 3) : 3 * ((row >> 2) & 1))));
+        }
+        t_.bAh = reinterpret_cast<const char*>(p.Ahi + aoff + (long)t_.m0 * p.lda);
+        t_.bAl = reinterpret_cast<const char*>(p.Alo + aoff + (long)t_.m0 * p.lda);
+        t_.bWh = reinterpret_cast<const char*>(p.Whi + woff + (long)t_.n0 * p.ldw);
+        t_.bWl = reinterpret_cast<const char*>(p.Wlo + woff + (long)t_.n0 * p.ldw);
+    };
+    Tile cur, nxt;
+    decode(tile_i, cur);
+    nxt = cur;
+
+    // k-tile t of tile T_'s A / W operand into ring slot sl_; piece q_ of the wave's NA / NWP.  t is clamped to the last k-tile:
+    // where a stream has no successor (the last output tile of a workgroup, or K shorter than the ring) the surplus DMAs re-fetch
+    // a k-tile into a slot nobody reads again; the vmcnt(0) at the end of the kernel retires them -- no DMA may land after the
+    // workgroup has given up its LDS.
+#define DMA_A(q_, T_, t_, sl_)                                                                                              \
     {                                                                                                                       \
         const int tt_ = (t_) < nk ? (t_) : nk - 1;                                                                          \
         const unsigned d_ = lds0 + 2u * (unsigned)((sl_) * ABUF + ((q_) & 1) * DPA + 16 * (NDA * wave + ((q_) >> 1)) * SBK); \
-        DMA16((((q_) & 1) ? bAl : bAh) + (long)tt_ * (2 * SBK), va[(q_) >> 1], d_);                                         \
+        DMA16((((q_) & 1) ? (T_).bAl : (T_).bAh) + (long)tt_ * (2 * SBK), (T_).va[(q_) >> 1], d_);                          \
     }
-#define DMA_W(q_, t_, sl_)                                                                                                  \
+#define DMA_W(q_, T_, t_, sl_)                                                                                              \
     {                                                                                                                       \
         const int tt_ = (t_) < nk ? (t_) : nk - 1;                                                                          \
         const int u_ = TERMS == 3 ? (q_) >> 1 : (q_);                                                                       \
         const int pl_ = TERMS == 3 ? (q_) & 1 : 0;                                                                          \
         if (WPIECES % NW_ == 0 || NDW * wave + u_ < WPIECES) {                                                              \
             const unsigned d_ = lds0 + 2u * (unsigned)(AST * ABUF + (sl_) * WBUF + pl_ * DPW + 16 * (NDW * wave + u_) * SBK); \
-            DMA16((pl_ ? bWl : bWh) + (long)tt_ * (2 * SBK), vw[u_], d_);                                                   \
+            DMA16((pl_ ? (T_).bWl : (T_).bWh) + (long)tt_ * (2 * SBK), (T_).vw[u_], d_);                                    \
         }                                                                                                                   \
     }
-
-    f32x4 acc16[4][NJ];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     [[maybe_unused]] unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, rt0 = 0, rt1 = 0;
 #ifdef LOCO_GEMM_STAMPS
@@ -361,15 +373,14 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #define A_STEP() (unsigned)(sa + 1 == AST ? -(AST - 1) * 2 * ABUF : 2 * ABUF)
 #define W_STEP() (unsigned)(sw + 1 == WST ? -(WST - 1) * 2 * WBUF : 2 * WBUF)
 
-#if LOCO_GEMM_PIPE
-    // ---- software-pipelined main loop: ONE barrier per k-tile, placed in the MIDDLE of the tile's MFMAs -----------------------
-    // A wave's fragments of tile kt are all in registers (or on their way) well before the tile's MFMAs end, so the barrier X_kt
-    // "every wave has read the slots of tile kt and every wave's DMA pieces of tile kt+1 have landed" can sit behind the reads of
-    // the last of the four row groups.  Behind it the slots of tile kt are re-filled (W tile kt + WST, A tile kt + AST) and -- no
-    // further barrier needed -- the fragments of tile kt+1 are read while the last row group's MFMAs run: A row group 0 into the
-    // free A slot, each W sub-tile into the registers of the sub-tile that has just been multiplied for the last time.  The
-    // matrix pipe has MFMAs queued on both sides of the barrier; a loop that stops at its barrier with empty registers pays
-    // DMA issue + LDS latency (~430 of ~3 500 cycles per k-tile) before the next tile's first MFMA.
+    // ---- software-pipelined k-loop: ONE barrier per k-tile, placed in the MIDDLE of the tile's MFMAs ---------------------------
+    // A wave's fragments of k-tile kt are all in registers (or on their way) well before the tile's MFMAs end, so the barrier X_kt
+    // "every wave has read the slots of k-tile kt and every wave's DMA pieces of k-tile kt+1 have landed" can sit behind the reads
+    // of the last of the four row groups.  Behind it the slots of k-tile kt are re-filled (W k-tile kt + WST, A k-tile kt + AST)
+    // and -- no further barrier needed -- the fragments of k-tile kt+1 are read while the last row group's MFMAs run: A row
+    // group 0 into the free A slot, each W sub-tile into the registers of the sub-tile that has just been multiplied for the last
+    // time.  The matrix pipe has MFMAs queued on both sides of the barrier; a loop that stops at its barrier with empty
+    // registers pays DMA issue + LDS latency (~430 of ~3 500 cycles per k-tile) before the next k-tile's first MFMA.
     // The DMA instructions are spread over the MFMA blocks behind the barrier: issued back to back they keep every wave of
     // the SIMD out of the matrix pipe at the same time (an LDS-DMA instruction holds its wave for 60-180 cycles).
     constexpr int JH = (NJ + 1) / 2;
@@ -377,136 +388,161 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     constexpr int NBLK = 1 + NG;       // MFMA blocks behind the barrier: the rest of row group 2, then row group 3 pair by pair
     constexpr int NPC = NWP + NA;      // DMA pieces behind the barrier: W first (it must have landed one barrier earlier than A)
     h8 ah[2], al[2], wh[NJ], wl[NJ];
+    f32x4 acc16[4][NJ];
 #pragma unroll
     for (int t = 0; t < WST; ++t)
 #pragma unroll
-        for (int q = 0; q < NWP; ++q) DMA_W(q, t, t)
+        for (int q = 0; q < NWP; ++q) DMA_W(q, cur, t, t)
 #pragma unroll
     for (int t = 0; t < AST; ++t)
 #pragma unroll
-        for (int q = 0; q < NA; ++q) DMA_A(q, t, t)
-    // Tile 0 and every W tile of the prologue have landed.  With three W slots the A pieces of tile 1 must have landed too: the
-    // in-loop wait leaves "the youngest NA + NWP" in flight, which in steady state are W and A of tile kt+2 but right after this
-    // prologue (all W first, then all A) would be the A pieces of tiles 1 AND 2.
+        for (int q = 0; q < NA; ++q) DMA_A(q, cur, t, t)
+    // k-tile 0 and every W k-tile of the prologue have landed.  With three W slots the A pieces of k-tile 1 must have landed too:
+    // the in-loop wait leaves "the youngest NA + NWP" in flight, which in steady state are W and A of k-tile kt+2 but right after
+    // this prologue (all W first, then all A) would be the A pieces of k-tiles 1 AND 2.
     VMCNT_LGKM0((WST == 3 ? AST - 2 : AST - 1) * NA)
     __builtin_amdgcn_s_barrier();
     GEMM_STAMP(st1)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) RD_W(j)
     RD_A(0, 0)
-#define DMA_AFTER_BLOCK(b_)                                                       \
-    {                                                                             \
-        _Pragma("unroll") for (int q = 0; q < NPC; ++q)                           \
-            if (q * NBLK / NPC == (b_)) {                                         \
-                if (q < NWP) DMA_W(q < NWP ? q : 0, kt + WST, sw)                 \
-                else DMA_A(q < NWP ? 0 : q - NWP, kt + AST, sa)                   \
-            }                                                                     \
-        SB()                                                                      \
+    // the DMA stream: k-tile kt + AST (WST) of this output tile or, past its end, of the next one (selected per k-tile with scalar
+    // selects and one v_cndmask per piece offset: no branch inside the pinned loop body)
+#define DMA_AFTER_BLOCK(b_)                                                                     \
+    {                                                                                           \
+        _Pragma("unroll") for (int q = 0; q < NPC; ++q)                                         \
+            if (q * NBLK / NPC == (b_)) {                                                       \
+                if (q < NWP) DMA_W(q < NWP ? q : 0, sel, tW, sw)                                \
+                else DMA_A(q < NWP ? 0 : q - NWP, sel, tA, sa)                                  \
+            }                                                                                   \
+        SB()                                                                                    \
     }
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned a_step = A_STEP(), w_step = W_STEP();
-        // MFMA blocks between two pins hold two W sub-tiles (two independent accumulator chains of TERMS MFMAs each, which hipcc
-        // interleaves): three dependent MFMAs back to back leave the matrix pipe to the other waves of the SIMD for 2 x 16 cycles
-        SB()
-        MM(0, 0, 0)  // first: only fragments read a block ago are waited for here
-        if (NJ > 1) MM(0, 0, 1)
-        // (the empty asm pins these MFMAs here: instruction selection otherwise places the last one of a chain, a pure node whose
-        // only user is the loop-carried copy, at the END of the body -- across every sched_barrier -- and keeps the old A
-        // fragments alive for it)
-        asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][NJ > 1 ? 1 : 0]));
-        SB()
-        RD_A(1, 1)
-        SB()
-#pragma unroll
-        for (int j = 2; j < NJ; ++j) MM(0, 0, j)
-        SB()
-        RD_A(2, 0)
-        SB()
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) MM(1, 1, j)
-        SB()
-        RD_A(3, 1)
-        SB()
-#pragma unroll
-        for (int j = 0; j < JH; ++j) MM(2, 0, j)
-        SB()
-        // X_kt: this wave's reads of tile kt's slots are complete (lgkmcnt) and its DMA pieces of tile kt+1 have landed (vmcnt: what
-        // may stay in flight is what was issued last behind X_kt-1 and is not needed before X_kt+1 -- the A pieces of tile kt+2
-        // when the A ring is deeper than the W ring, both sides' when both rings hold three)
-        VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int j = JH; j < NJ; ++j) MM(2, 0, j)
-        SB()
-        DMA_AFTER_BLOCK(0)
-        a_ad += a_step;  // both sides now address tile kt+1's slots (after the last tile: stale bytes of a landed slot, never used)
-        w_ad += w_step;
-        RD_A(0, 0)
-        SB()
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) MM(3, 1, j)
-            SB()
-            DMA_AFTER_BLOCK(1 + g)
-#pragma unroll
-            for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) RD_W(j)
-            SB()
-        }
-        sa = sa + 1 == AST ? 0 : sa + 1;
-        sw = sw + 1 == WST ? 0 : sw + 1;
-        SB()
-    }
-#undef DMA_AFTER_BLOCK
-#else
-    // ---- plain main loop: fetch ahead, read all fragments, multiply, wait + barrier ------------------------------------------------
-    constexpr int LA = AST - 1, LW = WST - 1;  // k-tiles in flight beyond the one being multiplied
-#pragma unroll
-    for (int t = 0; t < LW; ++t)
-#pragma unroll
-        for (int q = 0; q < NWP; ++q) DMA_W(q, t, t)
-#pragma unroll
-    for (int t = 0; t < LA; ++t)
-#pragma unroll
-        for (int q = 0; q < NA; ++q) DMA_A(q, t, t)
-    VMCNT_LGKM0((LA - 1) * NA)
-    __builtin_amdgcn_s_barrier();
-    GEMM_STAMP(st1)
-    for (int kt = 0; kt < nk; ++kt) {
-        const unsigned a_step = A_STEP(), w_step = W_STEP();
-        {
-            const int swn = sw + LW >= WST ? sw + LW - WST : sw + LW, san = sa + LA >= AST ? sa + LA - AST : sa + LA;
-#pragma unroll
-            for (int q = 0; q < NWP; ++q) DMA_W(q, kt + LW, swn)
-#pragma unroll
-            for (int q = 0; q < NA; ++q) DMA_A(q, kt + LA, san)
-        }
-        h8 ah[4], al[4], wh[NJ], wl[NJ];
-        // fragment reads in the order the MFMAs below first need them
-        ah[0] = LDS_H8(a_ad, 0);
-        al[0] = LDS_H8(a_ad, DPA);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) RD_W(j)
-#pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            ah[i] = LDS_H8(a_ad, 16 * i * SBK);
-            al[i] = LDS_H8(a_ad, DPA + 16 * i * SBK);
-        }
+    for (;;) {
+        const bool has_next = wg_step > 0 && tile_i + wg_step < run_len;
+        if (has_next) decode(tile_i + wg_step, nxt);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) MM(i, i, j)
-        // retire tile kt+1: every fragment read this wave has issued (the slots are re-filled behind the barrier) and its DMA
-        // pieces of the next tile; the youngest A tile (both sides' with two three-slot rings) stays in flight
-        VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
-        __builtin_amdgcn_s_barrier();
-        a_ad += a_step;
-        w_ad += w_step;
-        sa = sa + 1 == AST ? 0 : sa + 1;
-        sw = sw + 1 == WST ? 0 : sw + 1;
+            for (int j = 0; j < NJ; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned a_step = A_STEP(), w_step = W_STEP();
+            const bool a_cur = kt + AST < nk, w_cur = kt + WST < nk;
+            const int tA = a_cur ? kt + AST : kt + AST - nk, tW = w_cur ? kt + WST : kt + WST - nk;
+            Tile sel;
+            sel.bAh = a_cur ? cur.bAh : nxt.bAh;
+            sel.bAl = a_cur ? cur.bAl : nxt.bAl;
+            sel.bWh = w_cur ? cur.bWh : nxt.bWh;
+            sel.bWl = w_cur ? cur.bWl : nxt.bWl;
+#pragma unroll
+            for (int u = 0; u < NDA; ++u) sel.va[u] = a_cur ? cur.va[u] : nxt.va[u];
+#pragma unroll
+            for (int u = 0; u < NDW; ++u) sel.vw[u] = w_cur ? cur.vw[u] : nxt.vw[u];
+            // MFMA blocks between two pins hold two W sub-tiles (two independent accumulator chains of TERMS MFMAs each, which hipcc
+            // interleaves): three dependent MFMAs back to back leave the matrix pipe to the other waves of the SIMD for 2 x 16 cycles
+            SB()
+            MM(0, 0, 0)  // first: only fragments read a block ago are waited for here
+            if (NJ > 1) MM(0, 0, 1)
+            // (the empty asm pins these MFMAs here: instruction selection otherwise places the last one of a chain, a pure node whose
+            // only user is the loop-carried copy, at the END of the body -- across every sched_barrier -- and keeps the old A
+            // fragments alive for it)
+            asm volatile("" : "+v"(acc16[0][0]), "+v"(acc16[0][NJ > 1 ? 1 : 0]));
+            SB()
+            RD_A(1, 1)
+            SB()
+#pragma unroll
+            for (int j = 2; j < NJ; ++j) MM(0, 0, j)
+            SB()
+            RD_A(2, 0)
+            SB()
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) MM(1, 1, j)
+            SB()
+            RD_A(3, 1)
+            SB()
+#pragma unroll
+            for (int j = 0; j < JH; ++j) MM(2, 0, j)
+            SB()
+            // X_kt: this wave's reads of k-tile kt's slots are complete (lgkmcnt) and its DMA pieces of k-tile kt+1 have landed (vmcnt:
+            // what may stay in flight is what was issued last behind X_kt-1 and is not needed before X_kt+1 -- the A pieces of k-tile
+            // kt+2 when the A ring is deeper than the W ring, both sides' when both rings hold three; stores of the previous output
+            // tile's epilogue are younger still and only make the wait longer, never shorter)
+            VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = JH; j < NJ; ++j) MM(2, 0, j)
+            SB()
+            DMA_AFTER_BLOCK(0)
+            a_ad += a_step;  // both sides now address the next k-tile's slots (past the end of the stream: stale bytes, never used)
+            w_ad += w_step;
+            RD_A(0, 0)
+            SB()
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) MM(3, 1, j)
+                SB()
+                DMA_AFTER_BLOCK(1 + g)
+#pragma unroll
+                for (int j = 2 * g; j < 2 * g + 2 && j < NJ; ++j) RD_W(j)
+                SB()
+            }
+            sa = sa + 1 == AST ? 0 : sa + 1;
+            sw = sw + 1 == WST ? 0 : sw + 1;
+            SB()
+        }
+        GEMM_STAMP(st2)
+
+        // Epilogue of the output tile `cur`.  The accumulators hold 2^k times the product (the weight planes are pre-scaled,
+        // GemmSplitArgs::out_scale): one exact multiply restores it.  amax = max|x| of what this lane writes into fp16 planes.
+        {
+            const int m0 = cur.m0, n0 = cur.n0, z1 = cur.z1, z2 = cur.z2;
+            const long coff = cur.coff;
+            const float osc = p.out_scale;
+            float amax = 0.f;
+            const unsigned seen = (OUT_SPLIT || EPI == kEpiQkvScatter) ? range_peek(p.range_slot) : 0u;  // early: its latency hides below
+            if (PERMW) {
+                // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 q4 + 4 j + e]
+                const int n = n0 + wn * 64 + 16 * q4;
+                if (n < p.N) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = m0 + wm * 64 + 16 * i + r16;
+                        if (m >= p.M) continue;
+                        f32x4 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = acc16[i][j < NJ ? j : 0] * osc;
+                            if (p.bias && n + 4 * j < p.N) v[j] += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n + 4 * j);
+                        }
+                        split_gemm_store16<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
+                    }
+                }
+                range_commit(p.range_slot, amax, seen);
+            } else {
+                // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m0 + wm * 64 + 16 * i + r16;
+                    if (m >= p.M) continue;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int n = n0 + wn * 64 + 16 * j + 4 * q4;
+                        if (n < p.N) {
+                            f32x4 v = acc16[i][j] * osc;
+                            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
+                            split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
+                        }
+                    }
+                }
+                if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        tile_i += wg_step;
     }
-#endif  // LOCO_GEMM_PIPE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus DMAs of the last k-tiles: none may land after this workgroup's LDS is given away
+#undef DMA_AFTER_BLOCK
 #undef A_STEP
 #undef W_STEP
 #undef SB
@@ -516,71 +552,22 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #undef LDS_H8
 #undef DMA_W
 #undef DMA_A
-    GEMM_STAMP(st2)
 #ifdef LOCO_GEMM_STAMPS
-#define GEMM_STAMPS_OUT()                                                                                                   \
-    {                                                                                                                       \
-        GEMM_STAMP(st3)                                                                                                     \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                    \
-        GEMM_STAMP(st4)                                                                                                     \
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");                                   \
-        if (g_gemm_stamps && tid == 0) {                                                                                    \
-            unsigned hw;                                                                                                    \
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));                                               \
-            unsigned long long* o_ = g_gemm_stamps + 8l * blockIdx.x;                                                       \
-            o_[0] = st1 - st0; o_[1] = st2 - st1; o_[2] = 0; o_[3] = st3 - st2; o_[4] = st4 - st3; o_[5] = rt0; o_[6] = rt1; \
-            o_[7] = hw;                                                                                                     \
-        }                                                                                                                   \
+    {
+        GEMM_STAMP(st3)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(st4)
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+        if (g_gemm_stamps && tid == 0) {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+            unsigned long long* o_ = g_gemm_stamps + 8l * blockIdx.x;
+            o_[0] = st1 - st0; o_[1] = st2 - st1; o_[2] = 0; o_[3] = st3 - st2; o_[4] = st4 - st3; o_[5] = rt0; o_[6] = rt1;
+            o_[7] = hw;
+        }
     }
-#else
-#define GEMM_STAMPS_OUT() {}
 #endif
-
-    // Epilogue.  The accumulators hold 2^k times the product (the weight planes are pre-scaled, GemmSplitArgs::out_scale):
-    // one exact multiply restores it.  amax = max|x| of what this lane writes into fp16 planes (range tracking).
-    const float osc = p.out_scale;
-    float amax = 0.f;
-    const unsigned seen = (OUT_SPLIT || EPI == kEpiQkvScatter) ? range_peek(p.range_slot) : 0u;  // early: its latency hides below
-    if (PERMW) {
-        // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 q4 + 4 j + e]
-        const int n = n0 + wn * 64 + 16 * q4;
-        if (n < p.N) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + 16 * i + r16;
-                if (m >= p.M) continue;
-                f32x4 v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc16[i][j] * osc;
-                    if (p.bias && n + 4 * j < p.N) v[j] += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n + 4 * j);
-                }
-                split_gemm_store16<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
-            }
-        }
-        range_commit(p.range_slot, amax, seen);
-        GEMM_STAMPS_OUT()
-        return;
-    }
-    // acc16[i][j][e] = C[m = m0 + wm*64 + 16 i + r16][n = n0 + wn*64 + 16 j + 4 q4 + e]
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + r16;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * q4;
-            if (n < p.N) {
-                f32x4 v = acc16[i][j] * osc;
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + z2 * p.sBias2 + n);
-                split_gemm_store<EPI, OUT_SPLIT>(p, v, coff, m, n, amax, z1, z2);
-            }
-        }
-    }
-    if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
-    GEMM_STAMPS_OUT()
 }
-#undef GEMM_STAMPS_OUT
 #undef VMCNT_LGKM0
 #undef DMA16
 
@@ -612,11 +599,18 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     const long nb = (long)tm * tn * a.nb1 * a.nb2;
     if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
     const bool sp = a.Chi != nullptr;
+    // Persistent form: one workgroup per CU slot (256 CUs x WPS-per-CU), each walking its XCD's run of tiles, when there are more
+    // tiles than slots and the k-loop is at least as long as the A ring (the DMA stream looks AST k-tiles ahead, into the next
+    // output tile at most).  LOCO_GEMM_NOPERSIST=1 (read per call) launches one workgroup per tile, for A/B runs and the stamp tool.
+    constexpr int slots = 256 * (WPS ? (4 * WPS) / (WM * WN) : 1);
+    const bool persist = nb > slots && a.K / SBK >= AST && !getenv("LOCO_GEMM_NOPERSIST");
+    const unsigned grid = persist ? (unsigned)slots : (unsigned)nb;
+    const int wg_step = persist ? slots / 8 : 0;
 #define TILE_LAUNCH(EPI)                                                                                                              \
-    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0, \
-                               s, a, tm, tn, (int)nb);                                                                                \
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS>), dim3((unsigned)nb), dim3(64 * WM * WN), 0,  \
-                            s, a, tm, tn, (int)nb);
+    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0, \
+                               s, a, tm, tn, (int)nb, wg_step);                                                                       \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0,  \
+                            s, a, tm, tn, (int)nb, wg_step);
     switch (a.epilogue) {
         case kEpiNone: TILE_LAUNCH(kEpiNone) break;
         case kEpiGelu: TILE_LAUNCH(kEpiGelu) break;
@@ -646,10 +640,10 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
         if (a.terms == 2)
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
-                               (int)nb);
+                               (int)nb, 0);
         else
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
-                               (int)nb);
+                               (int)nb, 0);
         return hipGetLastError();
     }
     // Split-K for grids that cannot fill the chip (one 5 s utterance: M = 249 -> 12 workgroups for the FFN's second GEMM,
