@@ -39,6 +39,23 @@ typedef __attribute__((address_space(3))) void* ax_lptr_t;
 #define AX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define AX_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Diagnostic build only (-DLOCO_ATTN_STAMPS, tools/attn_stamps.py): wave 0 of every workgroup sums, per segment of the loop body,
+// the s_memtime cycles it spent there (DMA issue + rescale / block 1 / blocks 2-3 / bookkeeping + band / wait + barrier).
+#ifdef LOCO_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#define AX_STAMP(k_)                                                                                                     \
+    {                                                                                                                    \
+        unsigned long long t_;                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        seg[k_] += t_ - tlast;                                                                                           \
+        tlast = t_;                                                                                                      \
+    }
+#else
+#define AX_STAMP(k_) {}
+#endif
+
 // p = exp2(s log2e + dsh) for a register pair; hi = fp16(p) by one cvt_pk, lo = fp16(p - hi) by one mixed-precision FMA per
 // element (fp32 p, fp16 hi: the difference is exact, so lo is rounded once, like the host-side split).
 __device__ __forceinline__ void ax_split_pair(const f32x2 pv, unsigned& hi, unsigned& lo) {
@@ -74,7 +91,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         head = rest - (rest / kHeads) * kHeads;
         b = rest / kHeads;
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: kept in an SGPR (the DMA asm takes "s" operands)
     const int r = lane & 31, h = lane >> 5;
     const int iw0 = qblk * AX_BQ + wave * 32;
     const int iq = iw0 + r;
@@ -105,28 +123,40 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     // banks: with one 128-byte row per lane the 16 lanes of a group must cover both row parities x 8 distinct pieces,
     // which is exactly what those three row bits separate (checked with SQ_LDS_BANK_CONFLICT = 0).
     const int drow = lane >> 3, dpos = lane & 7;
-    long kcol[2], vsrc[2];
+    // Eight DMA instructions per wave move one K tile and one V^T tile (hi + lo planes).  The loop issues them ONE AT A TIME between
+    // the MFMAs of block 1 (AX_DMA_PIECE): back to back at the top of the iteration they held the wave for ~1 000 of its ~5 200
+    // cycles per key tile with no MFMA of its own in flight (tools/attn_stamps.py).  Scalar-base form (global_load_lds_dwordx4 voffset, sbase; M0 = LDS address of the piece): the base
+    // = plane + tile origin is wave-uniform, the lane offset fits 32 bits.  The tile index is clamped to the last tile instead of
+    // branching: the surplus DMAs of the last two iterations re-fetch it into a slot whose tile has been consumed, and the
+    // vmcnt(0) that ends every iteration retires them.
+    const unsigned lds0 = (unsigned)(unsigned long)(ax_lptr_t)lds;
+    unsigned kvc[2], vvo[2];  // K: column part of the lane offset (the row part depends on the clamp at T); V^T: the whole offset
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int swz = (((2 * wave + i) & 3) << 1) | ((drow >> 1) & 1);
-        kcol[i] = (long)head * kHeadDim + 8 * (dpos ^ swz);
-        vsrc[i] = ((long)b * kHidden + head * kHeadDim + 8 * (2 * wave + i) + drow) * Tp + 8 * (dpos ^ swz);
+        kvc[i] = 2u * (unsigned)(head * kHeadDim + 8 * (dpos ^ swz));
+        vvo[i] = 2u * (unsigned)((8 * (2 * wave + i) + drow) * Tp + 8 * (dpos ^ swz));
     }
-#define AX_DMA_K(t_, stg_)                                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                 \
-        int j_ = (t_) * AX_BK + 8 * (2 * wave + i_) + drow;                                                            \
-        j_ = j_ < T ? j_ : T - 1;                                                                                      \
-        const long go_ = ((long)b * T + j_) * kHidden + kcol[i_];                                                         \
-        _Float16* d_ = lds + (stg_) * AX_STG + 8 * (2 * wave + i_) * kHeadDim;                                         \
-        __builtin_amdgcn_global_load_lds((ax_gptr_t)(khi + go_), (ax_lptr_t)d_, 16, 0, 0);                             \
-        __builtin_amdgcn_global_load_lds((ax_gptr_t)(klo + go_), (ax_lptr_t)(d_ + AX_PL), 16, 0, 0);                   \
-    }
-#define AX_DMA_V(t_, stg_)                                                                                             \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                                 \
-        const long go_ = vsrc[i_] + (long)(t_) * AX_BK;                                                                \
-        _Float16* d_ = lds + (2 + (stg_)) * AX_STG + 8 * (2 * wave + i_) * AX_BK;                                      \
-        __builtin_amdgcn_global_load_lds((ax_gptr_t)(vthi + go_), (ax_lptr_t)d_, 16, 0, 0);                            \
-        __builtin_amdgcn_global_load_lds((ax_gptr_t)(vtlo + go_), (ax_lptr_t)(d_ + AX_PL), 16, 0, 0);                  \
+    const char* const kbase_h = reinterpret_cast<const char*>(khi + (long)b * T * kHidden);
+    const char* const kbase_l = reinterpret_cast<const char*>(klo + (long)b * T * kHidden);
+    const char* const vbase_h = reinterpret_cast<const char*>(vthi + ((long)b * kHidden + head * kHeadDim) * Tp);
+    const char* const vbase_l = reinterpret_cast<const char*>(vtlo + ((long)b * kHidden + head * kHeadDim) * Tp);
+#define AX_DMA16(base_, voff_, ldsb_) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#define AX_DMA_PIECE(pc_, tk_, tv_, kslot_, vslot_)                                                                          \
+    {                                                                                                                        \
+        const int i_ = ((pc_) >> 1) & 1, pl_ = (pc_) & 1;                                                                    \
+        if ((pc_) < 4) {                                                                                                     \
+            const int rmax_ = T - 1 - (tk_) * AX_BK; /* rows of the tile past the last key read key T-1 (masked later) */    \
+            int row_ = 8 * (2 * wave + i_) + drow;                                                                           \
+            row_ = row_ < rmax_ ? row_ : rmax_;                                                                              \
+            const unsigned vo_ = (unsigned)row_ * (2u * kHidden) + kvc[i_];                                                  \
+            const unsigned d_ = lds0 + 2u * (unsigned)((kslot_) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * kHeadDim);    \
+            AX_DMA16((pl_ ? kbase_l : kbase_h) + (long)(tk_) * (AX_BK * kHidden * 2), vo_, d_);                              \
+        } else {                                                                                                             \
+            const unsigned d_ = lds0 + 2u * (unsigned)((2 + (vslot_)) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * AX_BK); \
+            AX_DMA16((pl_ ? vbase_l : vbase_h) + (long)(tv_) * (AX_BK * 2), vvo[i_], d_);                                    \
+        }                                                                                                                    \
     }
 
     // fragment addresses (halves, within a tile): row 32 x + r, piece (2 y + h) ^ swz(r); x = key sub-tile (K) or d half
@@ -149,17 +179,33 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
 
     // ---- relative-position bias, key mask, row max and the online-softmax bookkeeping for one tile's raw scores.
     //      mx_ is the max of the raw scores (valid for tiles with a constant bias and no mask; recomputed otherwise).
-#define AX_BAND(S_, st_)                                                                                               \
+    // The diagonal band (key tiles with |i - j| < 160 for some pair).  The table is read COALESCED -- lane (lq, lj) loads
+    // Qp[query 4u + lq][key lj of a 16-key group]: 16 consecutive keys are 16 consecutive floats -- and transposed to the
+    // accumulator layout (query on the lane) through a per-wave LDS scratch.  The 32 loads of tile t+1 are issued at the TOP of
+    // iteration t and land in registers while its MFMAs run; only the LDS transposition remains in the bookkeeping.  (Loaded
+    // right where they were needed, four dependent rounds of load -> LDS -> read cost ~2 900 cycles per band tile, 14 % of the
+    // kernel at T = 1499; per-lane 16-byte gathers straight into the accumulator layout need no LDS but doubled the L2
+    // requests and made the launch 30 % slower: tools/attn_stamps.py, tools/attn_bench.py.)
+    float bandv[2][2][8];
+#define AX_IS_BAND(tt_) (iw0 - ((tt_) * AX_BK + AX_BK - 1) < kRelMax - 1 && iw0 + 31 - (tt_) * AX_BK > -kRelMax)
+#define AX_BAND_LOAD(tt_)                                                                                              \
+    if (AX_IS_BAND(tt_)) {                                                                                             \
+        const float* qpb = qp + ((long)b * kHeads + head) * T * kRelN;                                                 \
+        const int lj = lane & 15, lq = lane >> 4;                                                                      \
+        _Pragma("unroll") for (int st_ = 0; st_ < 2; ++st_)                                                            \
+            _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                   \
+                const int j = (tt_) * AX_BK + 32 * st_ + 16 * half + lj;                                               \
+                _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                        \
+                    const int i = iw0 + 4 * u + lq;                                                                    \
+                    int rel = i - j;                                                                                   \
+                    rel = rel < -kRelMax ? -kRelMax : (rel > kRelMax - 1 ? kRelMax - 1 : rel);                         \
+                    bandv[st_][half][u] = qpb[(long)(i < T ? i : T - 1) * kRelN + rel + kRelMax];                      \
+                }                                                                                                      \
+            }                                                                                                          \
+    }
+#define AX_BAND_ADD(S_, st_)                                                                                           \
     _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                           \
-        const int j = j0 + 32 * (st_) + 16 * half + lj;                                                                \
-        float bv[8];                                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                                \
-            const int i = iw0 + 4 * u + lq;                                                                            \
-            int rel = i - j;                                                                                           \
-            rel = rel < -kRelMax ? -kRelMax : (rel > kRelMax - 1 ? kRelMax - 1 : rel);                                 \
-            bv[u] = qpb[(long)(i < T ? i : T - 1) * kRelN + rel + kRelMax];                                            \
-        }                                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bv[u];                              \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bandv[st_][half][u];                \
         __builtin_amdgcn_wave_barrier();                                                                               \
         _Pragma("unroll") for (int e8 = 0; e8 < 8; ++e8)                                                               \
             S_[8 * half + e8] += sc[r * 17 + (e8 & 3) + 8 * (e8 >> 2) + 4 * h];                                        \
@@ -178,10 +224,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             cb = c_future;                                                                                             \
         } else {                                                                                                       \
             float* sc = bias_stage[wave];                                                                              \
-            const float* qpb = qp + ((long)b * kHeads + head) * T * kRelN;                                             \
             const int lj = lane & 15, lq = lane >> 4;                                                                  \
-            AX_BAND(S0_, 0)                                                                                            \
-            AX_BAND(S1_, 1)                                                                                            \
+            AX_BAND_ADD(S0_, 0)                                                                                        \
+            AX_BAND_ADD(S1_, 1)                                                                                        \
             redo = true;                                                                                               \
         }                                                                                                              \
         if (j0 + AX_BK > nvalid) {                                                                                     \
@@ -209,10 +254,19 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         dsh = (cb - m_new) * kLog2e;                                                                                   \
     }
 
+#ifdef LOCO_ATTN_STAMPS
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, tlast, tstart;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstart) :: "memory");
+    tlast = tstart;
+#endif
     // ---- prologue: K(0), V(0), K(1) in flight; S(0) = K(0) Q^T and its bookkeeping
-    AX_DMA_K(0, 0)
-    AX_DMA_V(0, 0)
-    if (ntiles > 1) { AX_DMA_K(1, 1) }
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) AX_DMA_PIECE(pc, 0, 0, 0, 0)
+    {
+        const int t1 = ntiles > 1 ? 1 : 0;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) AX_DMA_PIECE(pc, t1, 0, 1, 0)
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -233,9 +287,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, sa0[e]);
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sa1[e]);
+        AX_BAND_LOAD(0)
         AX_FINISH_TILE(sa0, sa1, 0, mx)
     }
     __syncthreads();  // every wave has read K(0) before K(2) may land on it
+    AX_STAMP(5)
 
     // ---- main loop, software-pipelined inside each wave so that the matrix pipe and the vector ALU always have
     //      independent work from the SAME wave (two waves per SIMD cannot be relied on to fall into anti-phase):
@@ -246,8 +302,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
 #define AX_ITER(t_, SC0, SC1, SN0, SN1)                                                                                \
     {                                                                                                                  \
         const int tq = (t_);                                                                                           \
-        if (tq + 2 < ntiles) { AX_DMA_K(tq + 2, tq & 1) }                                                              \
-        if (tq + 1 < ntiles) { AX_DMA_V(tq + 1, (tq + 1) & 1) }                                                        \
+        const int tkn = tq + 2 < ntiles ? tq + 2 : ntiles - 1, tvn = tq + 1 < ntiles ? tq + 1 : ntiles - 1;             \
+        if (tq + 1 < ntiles) { AX_BAND_LOAD(tq + 1) }                                                                  \
         const _Float16* kb = lds + ((tq + 1) & 1) * AX_STG;                                                            \
         const _Float16* vb = lds + (2 + (tq & 1)) * AX_STG;                                                            \
         h8 kf[2][4]; /* [buffer][hi0, lo0, hi1, lo1] */                                                                \
@@ -263,6 +319,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         _Pragma("unroll") for (int e = 0; e < 16; ++e) { SN0[e] = 0.f; SN1[e] = 0.f; }                                 \
         u32x4 ph0[2], pl0[2], ph1[2], pl1[2];                                                                          \
         AX_PIN();                                                                                                      \
+        AX_STAMP(0)                                                                                                    \
         /* ---- block 1 */                                                                                             \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                             \
             if (ks + 1 < 4) {                                                                                          \
@@ -291,9 +348,14 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                     const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);                                            \
                     SC1[e0] = __builtin_amdgcn_exp2f(ax.x); SC1[e0 + 1] = __builtin_amdgcn_exp2f(ax.y);                \
                 }                                                                                                      \
+                if (n % 3 == 1) { /* K(t+2) into the slot of K(t), V(t+1) into the slot of V(t-1): both consumed */     \
+                    AX_PIN();                                                                                          \
+                    AX_DMA_PIECE(n / 3, tkn, tvn, tq & 1, (tq + 1) & 1)                                                \
+                }                                                                                                      \
                 AX_PIN();                                                                                              \
             }                                                                                                          \
         }                                                                                                              \
+        AX_STAMP(1)                                                                                                    \
         /* ---- blocks 2 and 3: 8 groups (st, s2, dt) of 3 MFMAs; V^T fragments one group ahead */                     \
         h8 vf[2][2]; /* [buffer][hi, lo] */                                                                            \
         vf[0][0] = AX_VF(vb, 0, 0, 0); vf[0][1] = AX_VF(vb, 0, 0, 1);                                                  \
@@ -329,9 +391,12 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             }                                                                                                          \
         }                                                                                                              \
         l_run = l_run * alpha + (ps2.x + ps2.y);                                                                       \
+        AX_STAMP(2)                                                                                                    \
         if (tq + 1 < ntiles) { AX_FINISH_TILE(SN0, SN1, tq + 1, mxr) }                                                 \
+        AX_STAMP(3)                                                                                                    \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         __syncthreads();                                                                                               \
+        AX_STAMP(4)                                                                                                    \
     }
 
     for (int t = 0; t < ntiles; t += 2) {
@@ -341,12 +406,22 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     }
 #undef AX_ITER
 #undef AX_FINISH_TILE
-#undef AX_BAND
-#undef AX_DMA_K
-#undef AX_DMA_V
+#undef AX_BAND_LOAD
+#undef AX_BAND_ADD
+#undef AX_IS_BAND
+#undef AX_DMA_PIECE
+#undef AX_DMA16
 #undef AX_KF
 #undef AX_VF
 
+#ifdef LOCO_ATTN_STAMPS
+    if (g_attn_stamps && tid == 0) {
+        unsigned long long* o_ = g_attn_stamps + 8l * blockIdx.x;
+        for (int k_ = 0; k_ < 6; ++k_) o_[k_] = seg[k_];
+        o_[6] = (unsigned long long)ntiles;
+        o_[7] = tlast - tstart;
+    }
+#endif
     // ---- normalise and store: o{0,1}[e] = O[iq][d = 32 dt + (e&3) + 8 (e>>2) + 4h]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -395,3 +470,9 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
 }
 
 }  // namespace loco
+
+#ifdef LOCO_ATTN_STAMPS
+extern "C" int loco_debug_set_attn_stamps(void* buf) {  // diagnostic build only: 8 x u64 per workgroup of the next launches
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(loco::g_attn_stamps), &buf, sizeof(buf));
+}
+#endif

@@ -18,6 +18,10 @@
 
 #include "loco_kernels.h"
 
+#ifndef LOCO_GEMM_HACK
+#define LOCO_GEMM_HACK 0  // timing-only diagnostic builds, see DMA16 below
+#endif
+
 namespace loco {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -129,7 +133,8 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
     if (!OUT_SPLIT && EPI != kEpiQkvScatter) {
         float* cp = p.C + coff + (long)m * p.ldc + n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(cp + 4 * j) = v[j];
+        for (int j = 0; j < 4; ++j)
+            if (LOCO_GEMM_HACK != 4 || p.M <= 0) *reinterpret_cast<f32x4*>(cp + 4 * j) = v[j];
         return;
     }
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -158,6 +163,7 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
         dh = p.Chi + o;
         dl = p.Clo + o;
     }
+    if (LOCO_GEMM_HACK == 4 && p.M > 0) return;
     *reinterpret_cast<h8*>(dh) = hi[0];
     *reinterpret_cast<h8*>(dh + 8) = hi[1];
     *reinterpret_cast<h8*>(dl) = lo[0];
@@ -203,8 +209,15 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 // the 16-wave form, a spill with a vmcnt(0) reload between the DMAs).  M0 = LDS byte address of the piece (wave-uniform); one wait
 // state between the SALU write of M0 and the DMA that reads it.  (M0 is a reserved register to hipcc, which rejects it as a clobber;
 // nothing else in this kernel uses it -- gfx9 DS instructions do not -- and tests/test_isa_patterns.py checks that.)
+// LOCO_GEMM_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = no LDS-DMA is issued (what does the
+// L2 -> LDS traffic cost?), 2 = row groups 1 and 3 re-use the A fragments of 0 and 2 (a quarter of the LDS reads gone), 4 = no
+// epilogue stores.
+#if LOCO_GEMM_HACK == 1
+#define DMA16(base_, voff_, ldsb_) asm volatile("" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#else
 #define DMA16(base_, voff_, ldsb_) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#endif
 #define VMCNT_LGKM0(n_)                                                                                              \
     {                                                                                                                \
         static_assert((n_) >= 0 && (n_) <= 12, "vmcnt value not listed");                                            \
@@ -351,10 +364,13 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     unsigned a_ad = lds0 + 2u * (unsigned)fa;
     unsigned w_ad = lds0 + 2u * (unsigned)(AST * ABUF + fw);
 #define LDS_H8(ad_, halves_) (*(lds_h8p)(unsigned long)((ad_) + 2u * (unsigned)(halves_)))
-#define RD_A(i_, s_)                                       \
-    {                                                      \
-        ah[s_] = LDS_H8(a_ad, 16 * (i_) * SBK);            \
-        al[s_] = LDS_H8(a_ad, DPA + 16 * (i_) * SBK);      \
+#define RD_A(i_, s_)                                                  \
+    if (LOCO_GEMM_HACK != 2 || ((i_) & 1) == 0) {                     \
+        ah[s_] = LDS_H8(a_ad, 16 * (i_) * SBK);                       \
+        al[s_] = LDS_H8(a_ad, DPA + 16 * (i_) * SBK);                 \
+    } else {                                                          \
+        ah[s_] = ah[1 - (s_)];                                        \
+        al[s_] = al[1 - (s_)];                                        \
     }
 #define RD_W(j_)                                                                         \
     {                                                                                    \

@@ -14,11 +14,12 @@ for a in sys.argv[1:]:
             libs["t" + t] = lib
             tiles["t" + t] = t
 for a in sys.argv[1:]:
-    if a.endswith(".so"):  # A/B another build inside the same process (same device, same clocks)
+    if a.endswith(".so"):  # A/B other builds inside the same process (same device, same clocks); several may be given
         alt = C.CDLL(os.path.abspath(a))
         alt.loco_op_gemm_f16x3.restype = lib.loco_op_gemm_f16x3.restype
         alt.loco_op_gemm_f16x3.argtypes = lib.loco_op_gemm_f16x3.argtypes
-        libs["alt"] = alt
+        nm = os.path.basename(a)[3:-3] if os.path.basename(a).startswith("lib") else os.path.basename(a)[:-3]
+        libs["alt" if "alt" not in libs and sum(x.endswith(".so") for x in sys.argv[1:]) == 1 else nm[:8]] = alt
 M = 47968
 shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
           ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True),
@@ -70,4 +71,4 @@ for name, m, n, k, epi, osplit in shapes:
     nb = bufs[name][9]
     for v in libs:
         t = sorted(res[(v, name)])[len(res[(v, name)]) // 2]
-        print(f"{v:4s} {name:11s} M={nb*m:8d} N={n:5d} K={k:5d} epi={epi} split_out={int(osplit)} {t:8.3f} ms  {2.0*nb*m*n*k/t/1e9:7.1f} TFLOP/s (algorithmic)")
+        print(f"{v:8s} {name:11s} M={nb*m:8d} N={n:5d} K={k:5d} epi={epi} split_out={int(osplit)} {t:8.3f} ms  {2.0*nb*m*n*k/t/1e9:7.1f} TFLOP/s (algorithmic)")
