@@ -268,6 +268,16 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
                        int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t nb1, int32_t nb2, int64_t sA1, int64_t sA2,
                        int64_t sC1, int64_t sC2, void* stream);
 
+/* A convolution layer (kernel = taps <= 3, any stride: lda = stride * Cin) as the same GEMM over overlapping input rows, the way
+ * loco_forward runs feature_encoder.conv_layers.1-6: A = input planes [B][Tin][Cin] (sA1 = Tin * Cin), output [B][Tout][N], and the
+ * k axis walked channel-block major -- k-tile = (32-channel block, tap) -- so that the taps of a block are consecutive k-tiles
+ * and an input row shared by neighbouring outputs is fetched from HBM once.  The weight planes must be in that order:
+ * loco_op_permute_conv_k turns [N][taps][Cin] (tap-major K, fp32) into [N][Cin/32][taps][32]; split it with loco_op_split_f16. */
+int loco_op_permute_conv_k(const float* w, float* out, int32_t N, int32_t taps, int32_t Cin, void* stream);
+int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, float* C, void* Chi,
+                            void* Clo, int32_t Tout, int32_t N, int32_t Cin, int32_t taps, int32_t epilogue, int32_t B, int64_t sA1,
+                            void* stream);
+
 /* The same GEMM with the split-K workspace loco_forward hands it for small problems (M <= 512 and a grid that cannot
  * fill the chip): K is cut into slices computed side by side, partial sums (fp32, >= loco_gemm_splitk_bytes()) are added in
  * a fixed order by a second kernel that applies the epilogue.  Larger problems ignore the workspace. */

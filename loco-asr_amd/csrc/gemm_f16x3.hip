@@ -86,6 +86,7 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
             const int tc = vt_col(t);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+                if (LOCO_GEMM_HACK == 5 && p.M > 0) continue;  // timing-only: what do the 2-byte transposed V stores cost?
                 p.Vthi[(row + e) * p.Tp + tc] = hi[e];
                 p.Vtlo[(row + e) * p.Tp + tc] = lo[e];
             }
@@ -211,7 +212,7 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 // nothing else in this kernel uses it -- gfx9 DS instructions do not -- and tests/test_isa_patterns.py checks that.)
 // LOCO_GEMM_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = no LDS-DMA is issued (what does the
 // L2 -> LDS traffic cost?), 2 = row groups 1 and 3 re-use the A fragments of 0 and 2 (a quarter of the LDS reads gone), 4 = no
-// epilogue stores.
+// epilogue stores, 5 = no transposed V stores in the q|k|v scatter.
 #if LOCO_GEMM_HACK == 1
 #define DMA16(base_, voff_, ldsb_) asm volatile("" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 #else
@@ -238,7 +239,8 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 
 template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
-                                                                                                  int tiles_n, int nblk, int wg_step) {
+                                                                                                  int tiles_n, int nblk, int wg_step,
+                                                                                                  int col_group) {
     constexpr int DBM = 64 * WM, DBN = 64 * WN, NW_ = WM * WN;
     constexpr int DPA = DBM * SBK, DPW = DBN * SBK;          // halves per A / W plane of one k-tile
     constexpr int ABUF = 2 * DPA, WBUF = 2 * DPW;            // halves per ring slot (hi plane, lo plane)
@@ -288,17 +290,33 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     struct Tile {
         const char *bAh, *bAl, *bWh, *bWl;
         unsigned va[NDA], vw[NDW];
-        int m0, n0, z1, z2;
+        int m0, n0, z1, z2, kt0;
         long coff;
     };
     auto decode = [&](int i, Tile& t_) {
+        // Tile order inside a batch item: column tiles in groups of col_group, row tile next, group last.  The 32 workgroups of
+        // an XCD that run side by side then cover (32 / col_group) row tiles x col_group column tiles instead of a few rows x ALL
+        // columns: every A k-slice fetched into the L2 serves col_group tiles and every W k-slice 32 / col_group -- for square
+        // tiles the L2-miss bytes A (tiles_n / c) + W (tiles_m c / 32) are least at c = sqrt(32) (FFN1: 810 -> 626 MB per launch).
         const int t = run_start + i;
-        const int nt = t % tiles_n;
-        const int rest = t / tiles_n;
-        const int mt = rest % tiles_m;
-        const int z = rest / tiles_m;
+        const int per_z = tiles_m * tiles_n;
+        const int z = t / per_z;
+        const int tz = t - z * per_z;
+        const int full = tiles_n / col_group;  // complete column groups
+        int g = tz / (tiles_m * col_group), rem, width;
+        if (g < full) {
+            rem = tz - g * tiles_m * col_group;
+            width = col_group;
+        } else {
+            g = full;
+            rem = tz - full * tiles_m * col_group;
+            width = tiles_n - full * col_group;
+        }
+        const int mt = rem / width;
+        const int nt = g * col_group + (rem - mt * width);
         t_.z1 = z / p.nb2;
         t_.z2 = z % p.nb2;
+        t_.kt0 = t_.z2 * p.kt_per_z2;
         const long aoff = t_.z1 * p.sA1 + t_.z2 * p.sA2;
         const long woff = t_.z2 * p.sW2;
         t_.coff = t_.z1 * p.sC1 + t_.z2 * p.sC2;
@@ -331,11 +349,18 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     // where a stream has no successor (the last output tile of a workgroup, or K shorter than the ring) the surplus DMAs re-fetch
     // a k-tile into a slot nobody reads again; the vmcnt(0) at the end of the kernel retires them -- no DMA may land after the
     // workgroup has given up its LDS.
+    // byte offset of A's k-tile t: plain, or (GemmSplitArgs::ktaps) channel block t / ktaps of tap t % ktaps
+    const int ktaps = p.ktaps, kchan2 = 2 * (p.kchan ? p.kchan : p.K / (p.ktaps > 0 ? p.ktaps : 1));
+    auto a_koff = [&](int t) -> long {  // branch-free: ktaps is 1, 2 or 3 (checked by the launcher); t < 32768
+        const int cb3 = (int)(((unsigned)t * 0xAAABu) >> 17), cb2 = t >> 1;
+        const int cb = ktaps == 3 ? cb3 : (ktaps == 2 ? cb2 : t);
+        return (long)(t - cb * ktaps) * kchan2 + (long)cb * (2 * SBK);
+    };
 #define DMA_A(q_, T_, t_, sl_)                                                                                              \
     {                                                                                                                       \
         const int tt_ = (t_) < nk ? (t_) : nk - 1;                                                                          \
         const unsigned d_ = lds0 + 2u * (unsigned)((sl_) * ABUF + ((q_) & 1) * DPA + 16 * (NDA * wave + ((q_) >> 1)) * SBK); \
-        DMA16((((q_) & 1) ? (T_).bAl : (T_).bAh) + (long)tt_ * (2 * SBK), (T_).va[(q_) >> 1], d_);                          \
+        DMA16((((q_) & 1) ? (T_).bAl : (T_).bAh) + a_koff((T_).kt0 + tt_), (T_).va[(q_) >> 1], d_);                         \
     }
 #define DMA_W(q_, T_, t_, sl_)                                                                                              \
     {                                                                                                                       \
@@ -445,6 +470,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
             const bool a_cur = kt + AST < nk, w_cur = kt + WST < nk;
             const int tA = a_cur ? kt + AST : kt + AST - nk, tW = w_cur ? kt + WST : kt + WST - nk;
             Tile sel;
+            sel.kt0 = a_cur ? cur.kt0 : nxt.kt0;
             sel.bAh = a_cur ? cur.bAh : nxt.bAh;
             sel.bAl = a_cur ? cur.bAl : nxt.bAl;
             sel.bWh = w_cur ? cur.bWh : nxt.bWh;
@@ -622,11 +648,14 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     const bool persist = nb > slots && a.K / SBK >= AST && !getenv("LOCO_GEMM_NOPERSIST");
     const unsigned grid = persist ? (unsigned)slots : (unsigned)nb;
     const int wg_step = persist ? slots / 8 : 0;
+    // column tiles per group of the in-XCD tile order (see the kernel's decode): the divisor-like value nearest sqrt(32)
+    const int ngroups = (tn + 5) / 6;
+    const int col_group = getenv("LOCO_GEMM_NOCOLGROUP") ? tn : (tn + ngroups - 1) / ngroups;
 #define TILE_LAUNCH(EPI)                                                                                                              \
     if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0, \
-                               s, a, tm, tn, (int)nb, wg_step);                                                                       \
+                               s, a, tm, tn, (int)nb, wg_step, col_group);                                                            \
     else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0,  \
-                            s, a, tm, tn, (int)nb, wg_step);
+                            s, a, tm, tn, (int)nb, wg_step, col_group);
     switch (a.epilogue) {
         case kEpiNone: TILE_LAUNCH(kEpiNone) break;
         case kEpiGelu: TILE_LAUNCH(kEpiGelu) break;
@@ -656,16 +685,17 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
         if (a.terms == 2)
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
-                               (int)nb, 0);
+                               (int)nb, 0, 1);
         else
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
-                               (int)nb, 0);
+                               (int)nb, 0, 1);
         return hipGetLastError();
     }
     // Split-K for grids that cannot fill the chip (one 5 s utterance: M = 249 -> 12 workgroups for the FFN's second GEMM,
     // each walking K = 3072 in 96 dependent steps that are bound by HBM latency, not bandwidth): the K range is cut into ks
     // slices computed as a batch dimension of the same kernel (fp32 partial sums in a workspace), then summed in a fixed
     // order -- bitwise reproducible -- by a reduction kernel that applies the epilogue.
+    if (a.ktaps < 1 || a.ktaps > 3 || (!a.kchan && a.K % (a.ktaps * SBK) != 0) || a.K / SBK >= 32768) return hipErrorInvalidValue;
     if (a.splitk_ws && a.nb1 * a.nb2 == 1 && a.M <= kSplitKMaxM) {
         const int bm = a.M >= 1024 ? 256 : 128;  // the tile the dispatch below picks for this M (N tile 128)
         const int tm = (a.M + bm - 1) / bm, tn = (a.N + 127) / 128;
@@ -680,6 +710,11 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             b.C = a.splitk_ws; b.ldc = a.N;
             b.nb1 = 1; b.nb2 = ks; b.sA1 = 0; b.sC1 = 0;
             b.sA2 = kslice; b.sW2 = kslice; b.sC2 = (long)a.M * a.N; b.sBias2 = 0;
+            if (a.ktaps > 1) {  // channel-block-major k walk: a slice is a run of k-tiles of that walk, not a contiguous piece of an A row
+                b.sA2 = 0;
+                b.kt_per_z2 = kslice / SBK;
+                b.kchan = a.kchan ? a.kchan : a.K / a.ktaps;
+            }
             b.K = kslice;
             b.epilogue = kEpiNone;
             hipError_t err = launch_gemm_split(b, s);

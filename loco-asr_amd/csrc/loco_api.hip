@@ -308,13 +308,14 @@ int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _F
                    const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
                    int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0, int nb2 = 1, long sA2 = 0, long sC2 = 0,
                    const GemmSplitArgs* scatter = nullptr, const _Float16* Rhi = nullptr, const _Float16* Rlo = nullptr,
-                   float* range_slot = nullptr, int kid = K_GEMM_SPLIT) {
+                   float* range_slot = nullptr, int kid = K_GEMM_SPLIT, int ktaps = 1) {
     GemmSplitArgs a{Ahi, Alo, Wt.hi, Wt.lo, bias, R, C, Chi, Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epi};
     a.Rhi = Rhi;
     a.Rlo = Rlo;
     a.out_scale = Wt.inv_scale;
     a.range_slot = range_slot;
     a.co_scheduled = e->dual_active;
+    a.ktaps = ktaps;
     a.terms = (e->precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
@@ -587,7 +588,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         rc = run_gemm_split(e, s, ihi, ilo, (long)kConvS[i] * kConvDim, e->conv_s[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
                             last ? cout : nullptr, last ? nullptr : ohi, last ? nullptr : olo, kConvDim, (int)Tout, kConvDim,
                             kConvK[i] * kConvDim, kEpiGelu, B, Tin * kConvDim, Tout * kConvDim, 1, 0, 0, nullptr, nullptr, nullptr,
-                            last ? nullptr : slot(kConvNames[i]));
+                            last ? nullptr : slot(kConvNames[i]), K_GEMM_SPLIT, kConvK[i]);
         if (rc) return rc;
         float* t = cin;
         cin = cout;
@@ -938,7 +939,16 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     // fp16 hi/lo planes of every GEMM weight for precision mode f16x3 (378 MB; built unconditionally so that the
     // mode can be switched per forward)
     int rc = LOCO_OK;
-    for (int i = 1; speech && i < 7 && !rc; ++i) rc = make_split(e, e->conv_s[i], e->conv_w[i], (size_t)kConvDim * kConvDim * kConvK[i], s);
+    for (int i = 1; speech && i < 7 && !rc; ++i) {  // conv planes in the channel-block-major k order the GEMM walks (GemmSplitArgs::ktaps)
+        const size_t n = (size_t)kConvDim * kConvDim * kConvK[i];
+        float* tmpw = nullptr;
+        HIP_TRY(hipMalloc(&tmpw, n * sizeof(float)));
+        const hipError_t he = launch_permute_conv_k(e->conv_w[i], tmpw, kConvDim, kConvK[i], kConvDim, s);
+        if (he == hipSuccess) rc = make_split(e, e->conv_s[i], tmpw, n, s);
+        HIP_TRY(hipStreamSynchronize(s));
+        (void)hipFree(tmpw);
+        if (he != hipSuccess) return fail(LOCO_E_HIP, "permute_conv_k: %s", hipGetErrorString(he));
+    }
     if (speech && !rc) rc = make_split(e, e->proj_s, W(e, p + "feature_projection.projection.weight"), (size_t)kHidden * kConvDim, s);
     if (!rc) rc = make_split(e, e->pe_s, W(e, w + "embed_positions.pe_k.weight"), (size_t)kRelN * kHeadDim, s);
     if (speech && !rc) {  // positional conv weight re-laid [g][o][tap*48+i] for the conv-as-GEMM form, then split
@@ -1391,6 +1401,24 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
     if (K % 32 || (lda | ldw) & 7) return fail(LOCO_E_INVALID, "loco_op_gemm_f16x3: K %% 32 and lda/ldw %% 8 must be 0");
     GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, bias, R, C,
                     (_Float16*)Chi, (_Float16*)Clo, M, N, K, lda, ldw, ldc, ldr, nb1, nb2, sA1, sA2, sC1, sC2, epilogue};
+    HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_permute_conv_k(const float* w, float* out, int32_t N, int32_t taps, int32_t C, void* stream) {
+    if (!w || !out) return fail(LOCO_E_INVALID, "loco_op_permute_conv_k: null argument");
+    HIP_TRY(launch_permute_conv_k(w, out, N, taps, C, (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, float* C, void* Chi, void* Clo,
+                            int32_t Tout, int32_t N, int32_t Cin, int32_t taps, int32_t epilogue, int32_t B, int64_t sA1, void* stream) {
+    if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Chi)) return fail(LOCO_E_INVALID, "loco_op_conv_gemm_f16x3: null argument");
+    if (taps < 1 || taps > 3 || Cin % 32 || lda & 7) return fail(LOCO_E_INVALID, "loco_op_conv_gemm_f16x3: taps in 1..3, Cin %% 32 and lda %% 8");
+    const int K = taps * Cin;
+    GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, nullptr, nullptr, C,
+                    (_Float16*)Chi, (_Float16*)Clo, Tout, N, K, lda, K, N, 0, B, 1, sA1, 0, (int64_t)Tout * N, 0, epilogue};
+    a.ktaps = taps;
     HIP_TRY(launch_gemm_split(a, (hipStream_t)stream));
     return LOCO_OK;
 }

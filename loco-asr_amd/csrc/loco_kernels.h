@@ -80,6 +80,14 @@ struct GemmSplitArgs {
     // true while another stream of the same forward is launching kernels of its own (the two half-batch schedule): a partly filled
     // last round is then filled by that stream's workgroups, and the tile choice stops paying for whole rounds
     bool co_scheduled = false;
+    // Convolution as a GEMM over overlapping rows (A row t = input rows stride*t .. stride*t + ktaps - 1, K = ktaps * C): with
+    // ktaps > 1 the k axis is walked CHANNEL-BLOCK major -- k-tile kt = (32-channel block kt / ktaps, tap kt % ktaps) -- and the
+    // weight planes are stored in that order (launch_permute_conv_k).  The taps of one channel block are then consecutive
+    // k-tiles, so an input row that serves as tap 2 of output t and as tap 0 of output t+1 is fetched from HBM once and hit in
+    // L2 two k-tiles later, not re-fetched 32 k-tiles later after 1.5 MB per CU have gone through the L2 (conv1: 9.4 -> 6.3 GB).
+    int ktaps = 1;
+    int kchan = 0;       // channels per tap (0: K / ktaps); set by the split-K path, whose slices see only part of K
+    int kt_per_z2 = 0;   // split-K with ktaps > 1: slice z2 starts at k-tile z2 * kt_per_z2 of that walk (its A offset is not linear)
     // Range tracking: where the output is written as fp16 hi/lo planes, max|x| of what was written is folded into
     // range_slot[0..7] (see range_commit); null = not tracked.
     float* range_slot = nullptr;
@@ -255,6 +263,8 @@ hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* fr
 hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C, int k, hipStream_t s);  // [N,C,k]->[N,k*C]
 hipError_t launch_fold_pos_conv(const float* g, const float* v, float* out, hipStream_t s);  // -> [16][128][48][48]
 hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
+// conv weight [N][taps][C] (tap-major K) -> [N][C/32][taps][32] (the k order of GemmSplitArgs::ktaps)
+hipError_t launch_permute_conv_k(const float* src, float* dst, int N, int taps, int C, hipStream_t s);
 hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s);
 
 // sample-rate conversion (resample.hip)

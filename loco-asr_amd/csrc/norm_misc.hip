@@ -351,6 +351,22 @@ hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, 
     return hipGetLastError();
 }
 
+__global__ void permute_conv_k_kernel(const float* __restrict__ src, float* __restrict__ dst, long total, int taps, int C) {
+    const int K = taps * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kp = (int)(i % K);  // destination position: (cb, tap, cc)
+        const long n = i / K;
+        const int cc = kp & 31, tap = (kp >> 5) % taps, cb = (kp >> 5) / taps;
+        dst[i] = src[n * K + (long)tap * C + cb * 32 + cc];
+    }
+}
+
+hipError_t launch_permute_conv_k(const float* src, float* dst, int N, int taps, int C, hipStream_t s) {
+    if (N <= 0 || taps <= 0 || C <= 0 || (C & 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(permute_conv_k_kernel, dim3(1024), dim3(256), 0, s, src, dst, (long)N * taps * C, taps, C);
+    return hipGetLastError();
+}
+
 // Sinusoidal position table (HF modeling:305-321): row p = [sin(p*w_k) | cos(p*w_k)], w_k = exp(-k*ln(1e4)/383),
 // every step rounded to fp32 like the torch expression it restates; row 1 (the padding row) is zero.
 __global__ void sinusoid_table_kernel(float* __restrict__ tab, int rows) {

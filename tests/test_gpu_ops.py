@@ -389,6 +389,41 @@ def test_gemm_f16x3_batched_strided_conv_large():
     assert rel_l2(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("k,s_,Tin,B", [(3, 2, 24003, 9), (2, 2, 4001, 5), (3, 2, 700, 1)])
+def test_conv_gemm_f16x3_channel_block_major_k(k, s_, Tin, B):
+    """The form loco_forward runs conv layers 1-6 in: the k axis walked channel-block major (GemmSplitArgs::ktaps) over weights
+    permuted by loco_op_permute_conv_k -- against torch's conv1d in fp64, and against the plain tap-major GEMM on the same
+    operands (same products, another summation order: fp32-class agreement)."""
+    Cc = 512
+    x = hu("c5.x", (B, Tin, Cc))
+    w = hu("c5.w", (Cc, Cc, k), math.sqrt(2.0 / (Cc * k)))
+    Tout = (Tin - k) // s_ + 1
+    wt = w.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()  # [N][tap][C]
+    wtd = dev(wt)
+    wp = torch.empty_like(wtd)
+    check(lib().loco_op_permute_conv_k(ptr(wtd), ptr(wp), Cc, k, Cc, stream()))
+    ref_perm = wt.view(Cc, k, Cc // 32, 32).permute(0, 2, 1, 3).reshape(Cc, k * Cc)
+    assert torch.equal(wp.cpu(), ref_perm)
+    xhi, xlo = split16(x)
+    phi, plo = split16(wp.cpu())
+    whi, wlo = split16(wt)
+    out = {}
+    for name in ("blocked", "plain"):
+        chi = torch.empty(B * Tout, Cc, dtype=torch.float16, device="cuda")
+        clo = torch.empty_like(chi)
+        if name == "blocked":
+            check(lib().loco_op_conv_gemm_f16x3(ptr(xhi), ptr(xlo), s_ * Cc, ptr(phi), ptr(plo), None, ptr(chi), ptr(clo), Tout, Cc, Cc, k, 1, B,
+                                                Tin * Cc, stream()))
+        else:
+            check(lib().loco_op_gemm_f16x3(ptr(xhi), ptr(xlo), s_ * Cc, ptr(whi), ptr(wlo), k * Cc, None, None, Cc, None, ptr(chi), ptr(clo), Cc,
+                                           Tout, Cc, k * Cc, 1, B, 1, Tin * Cc, 0, Tout * Cc, 0, stream()))
+        out[name] = (chi.float() + clo.float()).view(B, Tout, Cc).cpu()
+    ref = F.conv1d(x.transpose(1, 2).double(), w.double(), stride=s_)
+    ref = (0.5 * ref * (1 + torch.erf(ref / math.sqrt(2)))).transpose(1, 2)
+    assert rel_l2(out["blocked"], ref) < 5e-6
+    assert rel_l2(out["blocked"], out["plain"]) < 2e-6
+
+
 def test_normalize_waveform_on_device_matches_hf_golden():
     """"next" row f-4: SpeechT5FeatureExtractor(do_normalize=True) on the device against HF's own output (fixture g7):
     values, padding, reproducibility, the mask-free form, and the feature extractor's deferred path end to end."""
