@@ -270,9 +270,10 @@ int loco_op_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void
 
 /* A convolution layer (kernel = taps <= 3, any stride: lda = stride * Cin) as the same GEMM over overlapping input rows, the way
  * loco_forward runs feature_encoder.conv_layers.1-6: A = input planes [B][Tin][Cin] (sA1 = Tin * Cin), output [B][Tout][N], and the
- * k axis walked channel-block major -- k-tile = (32-channel block, tap) -- so that the taps of a block are consecutive k-tiles
- * and an input row shared by neighbouring outputs is fetched from HBM once.  The weight planes must be in that order:
- * loco_op_permute_conv_k turns [N][taps][Cin] (tap-major K, fp32) into [N][Cin/32][taps][32]; split it with loco_op_split_f16. */
+ * k axis walked (64-channel block, tap slot, 32-channel half) with tap slots 0, 2, 1 -- so that the two uses of an input row shared
+ * by neighbouring outputs, and the two halves of every 128-byte line, are a k-tile or two apart and the row is fetched from HBM once.
+ * The weight planes must be in that order: loco_op_permute_conv_k turns [N][taps][Cin] (tap-major K, fp32) into
+ * [N][Cin/64][slot][2][32]; split it with loco_op_split_f16.  Cin % 64 == 0. */
 int loco_op_permute_conv_k(const float* w, float* out, int32_t N, int32_t taps, int32_t Cin, void* stream);
 int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, float* C, void* Chi,
                             void* Clo, int32_t Tout, int32_t N, int32_t Cin, int32_t taps, int32_t epilogue, int32_t B, int64_t sA1,

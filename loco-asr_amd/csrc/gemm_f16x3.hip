@@ -349,12 +349,16 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     // where a stream has no successor (the last output tile of a workgroup, or K shorter than the ring) the surplus DMAs re-fetch
     // a k-tile into a slot nobody reads again; the vmcnt(0) at the end of the kernel retires them -- no DMA may land after the
     // workgroup has given up its LDS.
-    // byte offset of A's k-tile t: plain, or (GemmSplitArgs::ktaps) channel block t / ktaps of tap t % ktaps
+    // byte offset of A's k-tile t: plain, or (GemmSplitArgs::ktaps > 1) the walk (64-channel block, tap slot, 32-channel half) with
+    // tap slots 0, 2, 1 -- loco_kernels.h.  Branch-free; ktaps is 1, 2 or 3 (checked by the launcher); t < 32768.
     const int ktaps = p.ktaps, kchan2 = 2 * (p.kchan ? p.kchan : p.K / (p.ktaps > 0 ? p.ktaps : 1));
-    auto a_koff = [&](int t) -> long {  // branch-free: ktaps is 1, 2 or 3 (checked by the launcher); t < 32768
-        const int cb3 = (int)(((unsigned)t * 0xAAABu) >> 17), cb2 = t >> 1;
-        const int cb = ktaps == 3 ? cb3 : (ktaps == 2 ? cb2 : t);
-        return (long)(t - cb * ktaps) * kchan2 + (long)cb * (2 * SBK);
+    auto a_koff = [&](int t) -> long {
+        const int q = t >> 1, half = t & 1;
+        const int cbp = ktaps == 3 ? (int)(((unsigned)q * 0xAAABu) >> 17) : (ktaps == 2 ? q >> 1 : q);
+        const int slot = q - cbp * ktaps;
+        const int tap = ktaps == 3 ? ((0x18 >> (2 * slot)) & 3) : slot;  // slots 0, 1, 2 -> taps 0, 2, 1
+        const long off = (long)tap * kchan2 + (long)(2 * cbp + half) * (2 * SBK);
+        return ktaps == 1 ? (long)t * (2 * SBK) : off;
     };
 #define DMA_A(q_, T_, t_, sl_)                                                                                              \
     {                                                                                                                       \
@@ -633,6 +637,65 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int
     if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);  // every lane of the wave gets here
 }
 
+// The same reduction for the fused q|k|v projection (kEpiQkvScatter), one 64-row x 64-column tile per workgroup.  The generic
+// kernel above hands a thread four columns of one row, which for the V third means four 2-byte stores into four different rows of
+// the transposed planes, a row pitch apart from its neighbours' -- 125 us for 1 497 rows, twice the GEMM it finishes (3 ms of a
+// 9.8 ms forward of 6 x 10 s run as two half-batches).  Here the V tiles go through an LDS tile and are written with the frame on
+// the lane: one wave instruction stores 64 consecutive frames of one V^T row (128 contiguous bytes, permuted inside aligned groups
+// of 16 by vt_col).
+__global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p, int ks) {
+    __shared__ float tile[64][65];
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const int c4 = tid & 15, r0 = tid >> 4;
+    float amax = 0.f;
+    const unsigned seen = range_peek(p.range_slot);
+    const int n = n0 + 4 * c4;
+    const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int ml = r0 + 16 * rr, m = m0 + ml;
+        if (m >= p.M) continue;
+        const float* part = p.splitk_ws + (long)m * p.N + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part);
+        for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (long)k * p.M * p.N);
+        v = v * p.out_scale + bias;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (n0 < 2 * kHidden) {  // q or k: plane rows, 8 bytes per thread, 128 contiguous bytes per 16 threads
+            unsigned h0, l0, h1, l1;
+            split_f16_2pairs(v[0], v[1], v[2], v[3], h0, l0, h1, l1);
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            const bool isq = n0 < kHidden;
+            const long o = (long)m * kHidden + (isq ? n : n - kHidden);
+            *reinterpret_cast<u32x2_t*>((isq ? p.Chi : p.Khi) + o) = u32x2_t{h0, h1};
+            *reinterpret_cast<u32x2_t*>((isq ? p.Clo : p.Klo) + o) = u32x2_t{l0, l1};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[ml][4 * c4 + e] = v[e];
+        }
+    }
+    if (n0 >= 2 * kHidden) {  // block-uniform
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        const int m = m0 + lane;
+        if (m < p.M) {
+            const int b = m / p.T, t = m - b * p.T;
+            const long col = vt_col(t);
+#pragma unroll 4
+            for (int dd = 0; dd < 16; ++dd) {
+                const int d = 16 * wave + dd;
+                const float x = tile[lane][d];
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)(x - (float)hi);
+                const long row = (long)b * kHidden + (n0 - 2 * kHidden) + d;
+                p.Vthi[row * p.Tp + col] = hi;
+                p.Vtlo[row * p.Tp + col] = lo;
+            }
+        }
+    }
+    range_commit(p.range_slot, amax, seen);
+}
+
 // One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, AST / WST ring slots, WPS as in the kernel template.
 template <int WM, int WN, int AST, int WST, int WPS, int TERMS = 3>
 static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
@@ -695,7 +758,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     // each walking K = 3072 in 96 dependent steps that are bound by HBM latency, not bandwidth): the K range is cut into ks
     // slices computed as a batch dimension of the same kernel (fp32 partial sums in a workspace), then summed in a fixed
     // order -- bitwise reproducible -- by a reduction kernel that applies the epilogue.
-    if (a.ktaps < 1 || a.ktaps > 3 || (!a.kchan && a.K % (a.ktaps * SBK) != 0) || a.K / SBK >= 32768) return hipErrorInvalidValue;
+    if (a.ktaps < 1 || a.ktaps > 3 || (!a.kchan && a.ktaps > 1 && a.K % (a.ktaps * 2 * SBK) != 0) || a.K / SBK >= 32768) return hipErrorInvalidValue;
     if (a.splitk_ws && a.nb1 * a.nb2 == 1 && a.M <= kSplitKMaxM) {
         const int bm = a.M >= 1024 ? 256 : 128;  // the tile the dispatch below picks for this M (N tile 128)
         const int tm = (a.M + bm - 1) / bm, tn = (a.N + 127) / 128;
@@ -728,7 +791,9 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
                 case kEpiNone: RED_LAUNCH(kEpiNone) break;
                 case kEpiGelu: RED_LAUNCH(kEpiGelu) break;
                 case kEpiResidual: RED_LAUNCH(kEpiResidual) break;
-                case kEpiQkvScatter: RED_LAUNCH(kEpiQkvScatter) break;
+                case kEpiQkvScatter:
+                    hipLaunchKernelGGL(splitk_reduce_qkv_kernel, dim3((unsigned)((a.M + 63) / 64), kQkv / 64), dim3(256), 0, s, a, ks);
+                    break;
                 default: return hipErrorInvalidValue;
             }
 #undef RED_LAUNCH

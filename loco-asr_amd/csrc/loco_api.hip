@@ -1414,7 +1414,7 @@ int loco_op_permute_conv_k(const float* w, float* out, int32_t N, int32_t taps, 
 int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, float* C, void* Chi, void* Clo,
                             int32_t Tout, int32_t N, int32_t Cin, int32_t taps, int32_t epilogue, int32_t B, int64_t sA1, void* stream) {
     if (!Ahi || !Alo || !Whi || !Wlo || (!C && !Chi)) return fail(LOCO_E_INVALID, "loco_op_conv_gemm_f16x3: null argument");
-    if (taps < 1 || taps > 3 || Cin % 32 || lda & 7) return fail(LOCO_E_INVALID, "loco_op_conv_gemm_f16x3: taps in 1..3, Cin %% 32 and lda %% 8");
+    if (taps < 1 || taps > 3 || Cin % 64 || lda & 7) return fail(LOCO_E_INVALID, "loco_op_conv_gemm_f16x3: taps in 1..3, Cin %% 64 and lda %% 8");
     const int K = taps * Cin;
     GemmSplitArgs a{(const _Float16*)Ahi, (const _Float16*)Alo, (const _Float16*)Whi, (const _Float16*)Wlo, nullptr, nullptr, C,
                     (_Float16*)Chi, (_Float16*)Clo, Tout, N, K, lda, K, N, 0, B, 1, sA1, 0, (int64_t)Tout * N, 0, epilogue};

@@ -81,10 +81,11 @@ struct GemmSplitArgs {
     // last round is then filled by that stream's workgroups, and the tile choice stops paying for whole rounds
     bool co_scheduled = false;
     // Convolution as a GEMM over overlapping rows (A row t = input rows stride*t .. stride*t + ktaps - 1, K = ktaps * C): with
-    // ktaps > 1 the k axis is walked CHANNEL-BLOCK major -- k-tile kt = (32-channel block kt / ktaps, tap kt % ktaps) -- and the
-    // weight planes are stored in that order (launch_permute_conv_k).  The taps of one channel block are then consecutive
-    // k-tiles, so an input row that serves as tap 2 of output t and as tap 0 of output t+1 is fetched from HBM once and hit in
-    // L2 two k-tiles later, not re-fetched 32 k-tiles later after 1.5 MB per CU have gone through the L2 (conv1: 9.4 -> 6.3 GB).
+    // ktaps > 1 the k axis is walked (64-channel block, tap slot, 32-channel half), tap slots in the order 0, 2, 1, and the weight
+    // planes are stored in that order (launch_permute_conv_k).  An input row that is tap 2 of output t is tap 0 of output t+1
+    // (stride 2): in a tap-major walk its two uses are 32 k-tiles apart, by when 1.5 MB per CU have gone through the XCD's
+    // 4 MiB L2 and the row is fetched again (conv1: 1.5 x its 6.3 GB operand).  Here they are two k-tiles apart, and the two
+    // 64-byte halves of every 128-byte line are consecutive k-tiles.
     int ktaps = 1;
     int kchan = 0;       // channels per tap (0: K / ktaps); set by the split-K path, whose slices see only part of K
     int kt_per_z2 = 0;   // split-K with ktaps > 1: slice z2 starts at k-tile z2 * kt_per_z2 of that walk (its A offset is not linear)
@@ -263,7 +264,7 @@ hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* fr
 hipError_t launch_relayout_conv_weight(const float* w, float* out, int N, int C, int k, hipStream_t s);  // [N,C,k]->[N,k*C]
 hipError_t launch_fold_pos_conv(const float* g, const float* v, float* out, hipStream_t s);  // -> [16][128][48][48]
 hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, hipStream_t s);
-// conv weight [N][taps][C] (tap-major K) -> [N][C/32][taps][32] (the k order of GemmSplitArgs::ktaps)
+// conv weight [N][taps][C] (tap-major K) -> [N][C/64][tap slot][2][32] (the k order of GemmSplitArgs::ktaps; slots = taps 0, 2, 1)
 hipError_t launch_permute_conv_k(const float* src, float* dst, int N, int taps, int C, hipStream_t s);
 hipError_t launch_sinusoid_table(float* tab, int rows, hipStream_t s);
 

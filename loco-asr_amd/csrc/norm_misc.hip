@@ -354,15 +354,17 @@ hipError_t launch_scale_copy(const float* src, float* dst, long n, float scale, 
 __global__ void permute_conv_k_kernel(const float* __restrict__ src, float* __restrict__ dst, long total, int taps, int C) {
     const int K = taps * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kp = (int)(i % K);  // destination position: (cb, tap, cc)
+        const int kp = (int)(i % K);  // destination position: k-tile kt = (64-channel block, tap slot, half), channel cc of the half
         const long n = i / K;
-        const int cc = kp & 31, tap = (kp >> 5) % taps, cb = (kp >> 5) / taps;
-        dst[i] = src[n * K + (long)tap * C + cb * 32 + cc];
+        const int cc = kp & 31, kt = kp >> 5;
+        const int half = kt & 1, q = kt >> 1, slot = q % taps, cbp = q / taps;
+        const int tap = taps == 3 ? ((0x18 >> (2 * slot)) & 3) : slot;  // slots 0, 1, 2 -> taps 0, 2, 1
+        dst[i] = src[n * K + (long)tap * C + (2 * cbp + half) * 32 + cc];
     }
 }
 
 hipError_t launch_permute_conv_k(const float* src, float* dst, int N, int taps, int C, hipStream_t s) {
-    if (N <= 0 || taps <= 0 || C <= 0 || (C & 31)) return hipErrorInvalidValue;
+    if (N <= 0 || taps <= 0 || taps > 3 || C <= 0 || (C & 63)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(permute_conv_k_kernel, dim3(1024), dim3(256), 0, s, src, dst, (long)N * taps * C, taps, C);
     return hipGetLastError();
 }
