@@ -237,7 +237,7 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
         else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                                            \
     }
 
-template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3>
+template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_f16x3_dma_kernel(GemmSplitArgs p, int tiles_m,
                                                                                                   int tiles_n, int nblk, int wg_step,
                                                                                                   int col_group) {
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 
     // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2); each XCD gets a contiguous
     // run of output tiles, column tile fastest, so that the tiles in flight on one L2 share their A rows.  PERSISTENT form
-    // (wg_step > 0: the grid is one workgroup per CU slot): a workgroup walks its XCD's run with stride wg_step, and the DMA
+    // (template flag PERSIST and wg_step > 0: the grid is one workgroup per CU slot): a workgroup walks its XCD's run with stride wg_step, and the DMA
     // stream simply runs on into the next output tile -- its first k-tiles are fetched while this tile's last ones are multiplied
     // and its epilogue runs, so no tile but the first waits for a cold prologue (6-9 % of a tile's life at K = 768 / 1536).
     const int xcd = blockIdx.x & 7;
@@ -463,8 +463,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         SB()                                                                                    \
     }
     for (;;) {
-        const bool has_next = wg_step > 0 && tile_i + wg_step < run_len;
-        if (has_next) decode(tile_i + wg_step, nxt);
+        const bool has_next = PERSIST && wg_step > 0 && tile_i + wg_step < run_len;
+        if (PERSIST && has_next) decode(tile_i + wg_step, nxt);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -472,17 +472,25 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned a_step = A_STEP(), w_step = W_STEP();
             const bool a_cur = kt + AST < nk, w_cur = kt + WST < nk;
-            const int tA = a_cur ? kt + AST : kt + AST - nk, tW = w_cur ? kt + WST : kt + WST - nk;
+            const int tA = (a_cur || !PERSIST) ? kt + AST : kt + AST - nk, tW = (w_cur || !PERSIST) ? kt + WST : kt + WST - nk;
+            // PERSIST: the stream's source is this output tile or, past its end, the next one (scalar selects and one v_cndmask per
+            // piece offset: no branch inside the pinned body).  Without it (the 16-wave form: its 128 VGPRs have no
+            // room for a second tile's lane offsets -- with them hipcc spilled INTO this loop and FFN1 / conv1 ran 8 % slower) the
+            // stream stays on this tile; DMA_A / DMA_W clamp the k-tile index, so its last slots are re-fetched and never read.
             Tile sel;
-            sel.kt0 = a_cur ? cur.kt0 : nxt.kt0;
-            sel.bAh = a_cur ? cur.bAh : nxt.bAh;
-            sel.bAl = a_cur ? cur.bAl : nxt.bAl;
-            sel.bWh = w_cur ? cur.bWh : nxt.bWh;
-            sel.bWl = w_cur ? cur.bWl : nxt.bWl;
+            if (PERSIST) {
+                sel.kt0 = a_cur ? cur.kt0 : nxt.kt0;
+                sel.bAh = a_cur ? cur.bAh : nxt.bAh;
+                sel.bAl = a_cur ? cur.bAl : nxt.bAl;
+                sel.bWh = w_cur ? cur.bWh : nxt.bWh;
+                sel.bWl = w_cur ? cur.bWl : nxt.bWl;
 #pragma unroll
-            for (int u = 0; u < NDA; ++u) sel.va[u] = a_cur ? cur.va[u] : nxt.va[u];
+                for (int u = 0; u < NDA; ++u) sel.va[u] = a_cur ? cur.va[u] : nxt.va[u];
 #pragma unroll
-            for (int u = 0; u < NDW; ++u) sel.vw[u] = w_cur ? cur.vw[u] : nxt.vw[u];
+                for (int u = 0; u < NDW; ++u) sel.vw[u] = w_cur ? cur.vw[u] : nxt.vw[u];
+            } else {
+                sel = cur;
+            }
             // MFMA blocks between two pins hold two W sub-tiles (two independent accumulator chains of TERMS MFMAs each, which hipcc
             // interleaves): three dependent MFMAs back to back leave the matrix pipe to the other waves of the SIMD for 2 x 16 cycles
             SB()
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
                 if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);
             }
         }
-        if (!has_next) break;
+        if (!PERSIST || !has_next) break;
         cur = nxt;
         tile_i += wg_step;
     }
@@ -707,17 +715,20 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     // Persistent form: one workgroup per CU slot (256 CUs x WPS-per-CU), each walking its XCD's run of tiles, when there are more
     // tiles than slots and the k-loop is at least as long as the A ring (the DMA stream looks AST k-tiles ahead, into the next
     // output tile at most).  LOCO_GEMM_NOPERSIST=1 (read per call) launches one workgroup per tile, for A/B runs and the stamp tool.
+    // The forms with 12 waves or fewer have the registers for it (168+ per wave); the 16-wave form (128) does not and runs one tile per
+    // workgroup (it gained 0-1 % from it; the 192x256 form gains 3-7 %, the table GEMM on the two-per-CU 128x128 form 12 %).
+    constexpr bool kPersist = WM * WN <= 12;
     constexpr int slots = 256 * (WPS ? (4 * WPS) / (WM * WN) : 1);
-    const bool persist = nb > slots && a.K / SBK >= AST && !getenv("LOCO_GEMM_NOPERSIST");
+    const bool persist = kPersist && nb > slots && a.K / SBK >= AST && !getenv("LOCO_GEMM_NOPERSIST");
     const unsigned grid = persist ? (unsigned)slots : (unsigned)nb;
     const int wg_step = persist ? slots / 8 : 0;
     // column tiles per group of the in-XCD tile order (see the kernel's decode): the divisor-like value nearest sqrt(32)
     const int ngroups = (tn + 5) / 6;
     const int col_group = getenv("LOCO_GEMM_NOCOLGROUP") ? tn : (tn + ngroups - 1) / ngroups;
 #define TILE_LAUNCH(EPI)                                                                                                              \
-    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0, \
+    if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS, kPersist>), dim3(grid), dim3(64 * WM * WN), 0, \
                                s, a, tm, tn, (int)nb, wg_step, col_group);                                                            \
-    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS>), dim3(grid), dim3(64 * WM * WN), 0,  \
+    else hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, false, WM, WN, AST, WST, 4, WPS, TERMS, kPersist>), dim3(grid), dim3(64 * WM * WN), 0,  \
                             s, a, tm, tn, (int)nb, wg_step, col_group);
     switch (a.epilogue) {
         case kEpiNone: TILE_LAUNCH(kEpiNone) break;

@@ -17,6 +17,6 @@ for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?Scra
         if k.group(1) in '14' and key not in seen:
             seen.add(key); print('epi',k.group(1),'split',k.group(2),'WMxWN',k.group(3),k.group(4),'AST/WST',k.group(5),k.group(6),'NJ',k.group(7),'WPS',k.group(8),'terms',k.group(9),'| vgpr',m.group(2),'agpr',m.group(3),'scratch',m.group(4),'occ',m.group(5),'lds',m.group(6))
 PY
-L=$(grep -n "^_ZN4loco21gemm_f16x3_dma_kernelILi1ELb1ELi4ELi4ELi3ELi2ELi4ELi0ELi3EEEvNS_13GemmSplitArgsEiiiii:" /tmp/asm/gemm_v.s | cut -d: -f1)
+L=$(grep -n "^_ZN4loco21gemm_f16x3_dma_kernelILi1ELb1ELi4ELi4ELi3ELi2ELi4ELi0ELi3ELb0EEEvNS_13GemmSplitArgsEiiiii:" /tmp/asm/gemm_v.s | cut -d: -f1)
 awk -v s=$L 'NR>=s && NR<=s+6500' /tmp/asm/gemm_v.s > /tmp/asm/ffn1_v.s
 grep -n "s_barrier\|^.LBB\|scratch_" /tmp/asm/ffn1_v.s | head -30

@@ -20,6 +20,12 @@ for a in sys.argv[1:]:
         alt.loco_op_gemm_f16x3.argtypes = lib.loco_op_gemm_f16x3.argtypes
         nm = os.path.basename(a)[3:-3] if os.path.basename(a).startswith("lib") else os.path.basename(a)[:-3]
         libs["alt" if "alt" not in libs and sum(x.endswith(".so") for x in sys.argv[1:]) == 1 else nm[:8]] = alt
+envvars = {}  # variant name -> environment variable set to "1" around its calls (the library reads its knobs on every launch)
+for a in sys.argv[1:]:
+    if a.startswith("--envvar="):  # e.g. --envvar=LOCO_GEMM_NOCOLGROUP: A/B a run-time knob inside this process
+        nm = a.split("=")[1]
+        libs["+" + nm[-7:]] = lib
+        envvars["+" + nm[-7:]] = nm
 M = 47968
 shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
           ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True),
@@ -65,8 +71,12 @@ for rnd in range(6):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             if v in tiles:
                 os.environ["LOCO_GEMM_TILE"] = tiles[v]
+            if v in envvars:
+                os.environ[envvars[v]] = "1"
             run(*s, lb=lb); e0.record(); run(*s, lb=lb); run(*s, lb=lb); e1.record(); torch.cuda.synchronize()
             if rnd: res[(v, s[0])].append(e0.elapsed_time(e1) / 2)
+            if v in envvars:
+                os.environ.pop(envvars[v])
 for name, m, n, k, epi, osplit in shapes:
     nb = bufs[name][9]
     for v in libs:
