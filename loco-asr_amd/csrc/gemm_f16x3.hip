@@ -625,14 +625,14 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #undef VMCNT_LGKM0
 #undef DMA16
 
-// Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns.
+// Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns; a grid of
+// at most 1024 blocks strides over the output (few, fat workgroups: one range atomic each, range_commit_block).
 template <int EPI, bool OUT_SPLIT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int ks) {
     const long n4 = (long)p.M * (p.N / 4);
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
     float amax = 0.f;
     const unsigned seen = (OUT_SPLIT || EPI == kEpiQkvScatter) ? range_peek(p.range_slot) : 0u;
-    if (i < n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const int m = (int)(i / (p.N / 4));
         const int n = 4 * (int)(i - (long)m * (p.N / 4));
         const float* part = p.splitk_ws + (long)m * p.N + n;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         split_gemm_store<EPI, OUT_SPLIT>(p, v, 0, m, n, amax);
     }
-    if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit(p.range_slot, amax, seen);  // every lane of the wave gets here
+    if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit_block(p.range_slot, amax, seen);  // every thread of the block gets here
 }
 
 // The same reduction for the fused q|k|v projection (kEpiQkvScatter), one 64-row x 64-column tile per workgroup.  The generic
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p,
             }
         }
     }
-    range_commit(p.range_slot, amax, seen);
+    range_commit_block(p.range_slot, amax, seen);
 }
 
 // One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, AST / WST ring slots, WPS as in the kernel template.
@@ -794,7 +794,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             hipError_t err = launch_gemm_split(b, s);
             if (err != hipSuccess) return err;
             const long n4 = (long)a.M * (a.N / 4);
-            const unsigned blocks = (unsigned)((n4 + 255) / 256);
+            const unsigned blocks = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
 #define RED_LAUNCH(EPI)                                                                                                  \
             if (split || EPI == kEpiQkvScatter) hipLaunchKernelGGL((splitk_reduce_kernel<EPI, true>), dim3(blocks), dim3(256), 0, s, a, ks); \
             else hipLaunchKernelGGL((splitk_reduce_kernel<EPI, false>), dim3(blocks), dim3(256), 0, s, a, ks);
@@ -909,7 +909,7 @@ __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* 
         reinterpret_cast<h4*>(hi)[i] = a;
         reinterpret_cast<h4*>(lo)[i] = c;
     }
-    range_commit(range_slot, amax, seen);
+    range_commit_block(range_slot, amax, seen);
 }
 
 hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot) {

@@ -155,6 +155,24 @@ __device__ __forceinline__ void range_commit(float* slot, float amax, unsigned s
         atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x & (kRangeShards - 1)), bits);
 }
 
+// The same for kernels of MANY small workgroups (the split-K reductions: thousands of 256-thread blocks that all start at once
+// and all peek a zero word): one atomic per workgroup instead of one per wave -- the wave maxima meet in LDS first.  Every thread
+// of the block must call it.  (With one atomic per wave the reduction behind FFN1's split-K GEMM took 72 us at 498 rows, 50 of
+// them in ~6 000 atomics on eight addresses: a quarter of a whole forward of the reference's 2 x 5 s batch.)
+__device__ __forceinline__ void range_commit_block(float* slot, float amax, unsigned seen) {
+    if (!slot) return;
+    __shared__ float wmax[16];
+    const float w = wave_max_nonneg(amax);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = wmax[0];
+        for (unsigned i = 1; i < (blockDim.x + 63) / 64; ++i) m = fmaxf(m, wmax[i]);
+        const unsigned bits = __float_as_uint(m);
+        if (bits > seen) atomicMax(reinterpret_cast<unsigned*>(slot) + (blockIdx.x & (kRangeShards - 1)), bits);
+    }
+}
+
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
 // Column of frame t in a V^T plane row: bits 2 and 3 of t are swapped, i.e. each aligned group of 16 frames is stored as
 // [0-3, 8-11, 4-7, 12-15].  The split-precision attention feeds P straight from the S^T accumulator registers into the
