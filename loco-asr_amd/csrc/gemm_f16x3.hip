@@ -219,22 +219,10 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 #define DMA16(base_, voff_, ldsb_) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 #endif
-#define VMCNT_LGKM0(n_)                                                                                              \
-    {                                                                                                                \
-        static_assert((n_) >= 0 && (n_) <= 12, "vmcnt value not listed");                                            \
-        if ((n_) == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                   \
-        else if ((n_) == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                              \
-        else if ((n_) == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");                            \
-        else if ((n_) == 11) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");                            \
-        else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");                                            \
+#define VMCNT_LGKM0(n_)                                                                              \
+    {                                                                                                \
+        static_assert((n_) >= 0 && (n_) <= 63, "vmcnt is a 6-bit field");                            \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n_) : "memory");                         \
     }
 
 template <int EPI, bool OUT_SPLIT, int WM, int WN, int AST, int WST, int NJ = 4, int WPS = 0, int TERMS = 3, bool PERSIST = false>
@@ -249,8 +237,8 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     constexpr int WPIECES = DBN / 16;
     constexpr int NA = 2 * NDA, NWP = (TERMS == 3 ? 2 : 1) * NDW;  // DMA instructions per wave per k-tile: A side, W side
     static_assert(NDA >= 1 && DBM % (16 * NW_) == 0, "tile too small for the wave count");
-    static_assert(AST >= WST && WST >= 2 && AST <= 3, "ring depths");
-    static_assert(WPIECES % NW_ == 0 || WST == 2, "uneven W pieces: no wait may leave W DMAs in flight");
+    static_assert((AST == WST && AST >= 2 && AST <= 5) || (AST == 3 && WST == 2), "ring depths: equal rings of 2-5 slots, or 3 A + 2 W");
+    static_assert(WPIECES % NW_ == 0 || (WST == 2 && AST == 3) || AST == 2, "uneven W pieces: no wait may leave W DMAs in flight");
     static_assert(TERMS == 3 || TERMS == 2, "terms");
     static_assert((size_t)(AST * ABUF + WST * WBUF) * 2 <= 160 * 1024, "LDS");
     static_assert(2 * (DPA + 16 * 3 * SBK) < 65536 && 2 * (DPW + 16 * 3 * SBK) < 65536, "fragment offsets are ds_read immediates");
@@ -434,18 +422,32 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     constexpr int NPC = NWP + NA;      // DMA pieces behind the barrier: W first (it must have landed one barrier earlier than A)
     h8 ah[2], al[2], wh[NJ], wl[NJ];
     f32x4 acc16[4][NJ];
+    // Waits leave "the youngest N instructions" in flight, so the ORDER of issue decides what a count means.  In the loop every
+    // barrier is followed by W(kt + WST) then A(kt + AST); for two equal rings of S slots the tiles kt+2 .. kt+S-1 of both sides
+    // may stay in flight at X_kt = (S - 2)(NA + NWP), provided the prologue issued tile by tile as well (W_t, A_t).  With three A
+    // slots over two W slots the prologue issues all W first (the 12-wave form's W pieces are uneven over the waves: no count
+    // may include them) and only the A pieces of the youngest tile stay in flight.
+    constexpr int kPendLoop = AST == WST ? (AST - 2) * (NA + NWP) : NA;
+    if (AST == WST) {
 #pragma unroll
-    for (int t = 0; t < WST; ++t)
+        for (int t = 0; t < AST; ++t) {
 #pragma unroll
-        for (int q = 0; q < NWP; ++q) DMA_W(q, cur, t, t)
+            for (int q = 0; q < NWP; ++q) DMA_W(q, cur, t, t)
 #pragma unroll
-    for (int t = 0; t < AST; ++t)
+            for (int q = 0; q < NA; ++q) DMA_A(q, cur, t, t)
+        }
+        VMCNT_LGKM0(WPIECES % NW_ == 0 ? (AST - 1) * (NA + NWP) : 0)  // k-tile 0 has landed
+    } else {
 #pragma unroll
-        for (int q = 0; q < NA; ++q) DMA_A(q, cur, t, t)
-    // k-tile 0 and every W k-tile of the prologue have landed.  With three W slots the A pieces of k-tile 1 must have landed too:
-    // the in-loop wait leaves "the youngest NA + NWP" in flight, which in steady state are W and A of k-tile kt+2 but right after
-    // this prologue (all W first, then all A) would be the A pieces of k-tiles 1 AND 2.
-    VMCNT_LGKM0((WST == 3 ? AST - 2 : AST - 1) * NA)
+        for (int t = 0; t < WST; ++t)
+#pragma unroll
+            for (int q = 0; q < NWP; ++q) DMA_W(q, cur, t, t)
+#pragma unroll
+        for (int t = 0; t < AST; ++t)
+#pragma unroll
+            for (int q = 0; q < NA; ++q) DMA_A(q, cur, t, t)
+        VMCNT_LGKM0((AST - 1) * NA)  // every W k-tile of the prologue and A k-tile 0 have landed
+    }
     __builtin_amdgcn_s_barrier();
     GEMM_STAMP(st1)
 #pragma unroll
@@ -517,10 +519,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
             for (int j = 0; j < JH; ++j) MM(2, 0, j)
             SB()
             // X_kt: this wave's reads of k-tile kt's slots are complete (lgkmcnt) and its DMA pieces of k-tile kt+1 have landed (vmcnt:
-            // what may stay in flight is what was issued last behind X_kt-1 and is not needed before X_kt+1 -- the A pieces of k-tile
-            // kt+2 when the A ring is deeper than the W ring, both sides' when both rings hold three; stores of the previous output
-            // tile's epilogue are younger still and only make the wait longer, never shorter)
-            VMCNT_LGKM0(AST == 3 ? (WST == 3 ? NA + NWP : NA) : 0)
+            // kPendLoop instructions -- the k-tiles beyond kt+1 -- may stay in flight; stores of the previous output tile's epilogue
+            // are younger still and only make the wait longer, never shorter)
+            VMCNT_LGKM0(kPendLoop)
             __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int j = JH; j < NJ; ++j) MM(2, 0, j)
@@ -844,7 +845,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         }
     }
     // ring depths: 256x256 -> three A slots + two W slots = 160 KiB; 192x256 -> 3 + 2 = 136 KiB; 256x128 and the one-per-CU
-    // 128x128 -> 3 + 3; the two-per-CU forms 2 + 2
+    // 128x128 -> 3 + 3 (five slots per side were tried for the latter: tile 8); the two-per-CU forms 2 + 2
     if (a.terms == 2) {  // precision mode "f16x2": the weights' lo plane is neither streamed nor multiplied
         switch (tile) {
             case 1: return launch_tile<4, 4, 3, 2, 0, 2>(a, s);
@@ -862,6 +863,8 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         case 3: return launch_tile<3, 2, 2, 2, 3>(a, s);
         case 4: return launch_tile<2, 2, 2, 2, 2>(a, s);
         case 5: return launch_tile<2, 2, 3, 3, 0>(a, s);
+        case 8: return launch_tile<2, 2, 5, 5, 0>(a, s);  // A/B: the small-M form with five slots per side (160 KiB): no faster --
+                                                          // its few workgroups are not waiting for their DMA stream
         case 6: return launch_tile<3, 4, 3, 2, 0>(a, s);
         case 7: return launch_tile<4, 4, 2, 2, 0>(a, s);  // A/B: the 256x256 form with two slots per side (128 KiB)
         default: return hipErrorInvalidValue;

@@ -348,7 +348,7 @@ def test_gemm_f16x3_every_tile_form_agrees_bit_for_bit(K):
     bd = dev(b)
     outs = {}
     try:
-        for tile in (2, 1, 3, 4, 5, 6, 7):
+        for tile in (2, 1, 3, 4, 5, 6, 7, 8):
             os.environ["LOCO_GEMM_TILE"] = str(tile)
             for rep in range(3):
                 chi = torch.zeros(M, N, dtype=torch.float16, device="cuda")
