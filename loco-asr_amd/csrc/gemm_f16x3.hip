@@ -212,9 +212,12 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 // nothing else in this kernel uses it -- gfx9 DS instructions do not -- and tests/test_isa_patterns.py checks that.)
 // LOCO_GEMM_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = no LDS-DMA is issued (what does the
 // L2 -> LDS traffic cost?), 2 = row groups 1 and 3 re-use the A fragments of 0 and 2 (a quarter of the LDS reads gone), 4 = no
-// epilogue stores, 5 = no transposed V stores in the q|k|v scatter.
+// epilogue stores, 5 = no transposed V stores in the q|k|v scatter, 6 = only waves 0-3 issue LDS-DMA (with tools/gemm_stamps.py).
 #if LOCO_GEMM_HACK == 1
 #define DMA16(base_, voff_, ldsb_) asm volatile("" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#elif LOCO_GEMM_HACK == 6  // only waves 0-3 (one per SIMD) issue their DMA pieces: do the four waves of a SIMD collide in DMA issue?
+#define DMA16(base_, voff_, ldsb_)                                                                                                  \
+    if (wave < 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 #else
 #define DMA16(base_, voff_, ldsb_) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
