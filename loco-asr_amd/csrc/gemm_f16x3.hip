@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
     // registers pays DMA issue + LDS latency (~430 of ~3 500 cycles per k-tile) before the next k-tile's first MFMA.
     // The DMA instructions are spread over the MFMA blocks behind the barrier: issued back to back they keep every wave of
     // the SIMD out of the matrix pipe at the same time (an LDS-DMA instruction holds its wave for 60-180 cycles).
-    constexpr int JH = (NJ + 1) / 2;
+    constexpr int JH = (NJ + 1) / 2;   // W sub-tiles of row group 2 multiplied BEFORE the barrier (all of them there: +1.5...4 % cycles per k-tile)
     constexpr int NG = (NJ + 1) / 2;   // pairs of W sub-tiles
     constexpr int NBLK = 1 + NG;       // MFMA blocks behind the barrier: the rest of row group 2, then row group 3 pair by pair
     constexpr int NPC = NWP + NA;      // DMA pieces behind the barrier: W first (it must have landed one barrier earlier than A)
