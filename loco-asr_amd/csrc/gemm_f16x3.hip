@@ -4,16 +4,16 @@
 //   A W^T ~= A_hi W_hi^T + A_lo W_hi^T + A_hi W_lo^T          (the dropped lo*lo term is ~2^-22 relative)
 //
 // Every partial product of two fp16 values is exact in the MFMA's fp32 accumulator, so the only errors are the
-// 22-bit hi+lo representation and the dropped term: the whole encoder lands at 2.7e-6 relative L2 of an fp64
-// evaluation, against 6.5e-7 for exact fp32 and 1.6e-3 for plain fp16 (BASELINE.md probe; emulation in DESIGN.md §8).
-// Three v_mfma_f32_32x32x16_f16 (32 cycles, 32 768 FLOP each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles,
+// 22-bit hi+lo representation and the dropped term: the whole encoder lands at ~1e-6 relative L2 of an fp64
+// evaluation, like exact fp32, against 1.6e-3 for plain fp16 (BASELINE.md probe).
+// Three v_mfma_f32_16x16x32_f16 (16 cycles, 16 384 FLOP each) replace four v_mfma_f32_32x32x2_f32 (64 cycles,
 // 4 096 FLOP each): 5.3x fewer matrix-pipe cycles per algorithmic FLOP.
 //
 // Operands arrive ALREADY split -- weights once at load time, activations by the epilogue of the kernel that
 // produced them (same bytes as fp32: 2+2) -- so this kernel moves exactly the bytes of the fp32 GEMM and spends
-// no VALU on conversion.  One kernel template (gemm_f16x3_dma_kernel, below) covers every shape: 256x256, 256x128 and
-// 128x128 tiles on an LDS ring filled by LDS-DMA, 64x64 per wave, D = W_tile * A_tile^T orientation; small problems add
-// split-K with a fixed-order reduction (launch_gemm_split).
+// no VALU on conversion.  One kernel template (gemm_f16x3_dma_kernel, below) covers every shape: 256x256, 192x256, 256x128 and
+// 128x128 tiles on two LDS rings (A, W) filled by LDS-DMA, 64x64 per wave, D = W_tile * A_tile^T orientation, a software-
+// pipelined k-loop with one barrier per k-tile; small problems add split-K with a fixed-order reduction (launch_gemm_split).
 #include <cstdlib>
 
 #include "loco_kernels.h"
