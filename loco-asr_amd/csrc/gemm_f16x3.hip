@@ -308,8 +308,9 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
         t_.z1 = z / p.nb2;
         t_.z2 = z % p.nb2;
         t_.kt0 = t_.z2 * p.kt_per_z2;
-        const long aoff = t_.z1 * p.sA1 + t_.z2 * p.sA2;
-        const long woff = t_.z2 * p.sW2;
+        const int z1o = t_.z1 / p.z1_inner, z1i = t_.z1 - z1o * p.z1_inner;
+        const long aoff = z1o * p.sA1 + z1i * p.sA1i + t_.z2 * p.sA2;
+        const long woff = z1i * p.sW1i + t_.z2 * p.sW2;
         t_.coff = t_.z1 * p.sC1 + t_.z2 * p.sC2;
         t_.m0 = mt * DBM;
         t_.n0 = nt * DBN;
@@ -708,6 +709,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p,
     range_commit_block(p.range_slot, amax, seen);
 }
 
+// The split-K reduction of the grouped positional conv: partial sums [clip][slice][group][frame][48], epilogue kEpiPosConv.
+__global__ __launch_bounds__(256) void splitk_reduce_posconv_kernel(GemmSplitArgs p, int ks) {
+    constexpr int n4s = kPosCg / 4;
+    const long total = (long)p.nb1 * p.nb2 * p.M * n4s;
+    float amax = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = 4 * (int)(i % n4s);
+        long rest = i / n4s;
+        const int m = (int)(rest % p.M);
+        rest /= p.M;
+        const int g = (int)(rest % p.nb2), b = (int)(rest / p.nb2);
+        const long gstride = (long)p.M * kPosCg, sstride = (long)p.nb2 * gstride;
+        const float* part = p.splitk_ws + ((long)b * ks * p.nb2 + g) * gstride + (long)m * kPosCg + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part);
+        for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + k * sstride);
+        v *= p.out_scale;
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + g * p.sBias2 + n);
+        split_gemm_store<kEpiPosConv, false>(p, v, b * p.sC1 + g * p.sC2, m, n, amax, b, g);
+    }
+}
+
 // One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, AST / WST ring slots, WPS as in the kernel template.
 template <int WM, int WN, int AST, int WST, int WPS, int TERMS = 3>
 static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
@@ -761,6 +783,39 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         const int tm = (a.M + 511) / 512;
         const long nb = (long)tm * a.nb1 * a.nb2;
         if (nb <= 0 || nb > 0x7fffffffL) return hipErrorInvalidValue;
+        // One or two short clips: 16 groups x B workgroups would each walk K = 6144 in 192 dependent k-tiles (200 us, the longest
+        // kernel of a 2 ms forward).  Split-K over the taps: the slice becomes the inner half of z1 (GemmSplitArgs::z1_inner),
+        // fp32 partial sums [clip][slice][group][frame][48], then splitk_reduce_posconv_kernel applies the epilogue.
+        if (a.splitk_ws && nb <= 64 && a.z1_inner == 1) {
+            // a FIXED slice count: a clip's result must not depend on how many neighbours share its batch (the summation order
+            // is part of the result), so within this regime every batch size takes the same eight slices of 24 k-tiles
+            const int ks = 8;
+            if (a.K % (ks * SBK) == 0 && (size_t)ks * a.nb1 * a.nb2 * a.M * kPosCg * sizeof(float) <= kSplitKBytes) {
+                GemmSplitArgs b = a;
+                const int kslice = a.K / ks;
+                b.splitk_ws = nullptr;
+                b.bias = nullptr; b.R = nullptr; b.out_scale = 1.0f; b.sin_table = nullptr; b.frames = nullptr;
+                b.C = a.splitk_ws; b.ldc = kPosCg;
+                b.nb1 = a.nb1 * ks; b.z1_inner = ks;
+                b.sA1i = kslice; b.sW1i = kslice;
+                b.sC1 = (long)a.nb2 * a.M * kPosCg; b.sC2 = (long)a.M * kPosCg;
+                b.K = kslice;
+                b.epilogue = kEpiNone;
+                const long nbp = (long)tm * b.nb1 * b.nb2;
+                if (a.terms == 2)
+                    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiNone, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nbp), dim3(512), 0, s, b, tm, 1,
+                                       (int)nbp, 0, 1);
+                else
+                    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiNone, false, 8, 1, 2, 2, 3>), dim3((unsigned)nbp), dim3(512), 0, s, b, tm, 1,
+                                       (int)nbp, 0, 1);
+                hipError_t err = hipGetLastError();
+                if (err != hipSuccess) return err;
+                const long n4 = (long)a.nb1 * a.nb2 * a.M * (kPosCg / 4);
+                const unsigned blocks = (unsigned)((n4 + 255) / 256 < 1024 ? (n4 + 255) / 256 : 1024);
+                hipLaunchKernelGGL(splitk_reduce_posconv_kernel, dim3(blocks), dim3(256), 0, s, a, ks);
+                return hipGetLastError();
+            }
+        }
         if (a.terms == 2)
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
                                (int)nb, 0, 1);

@@ -631,6 +631,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         a.out_scale = e->posg_s.inv_scale;
         a.terms = e->precision == 2 ? 2 : 3;
         a.sin_table = e->sin_tab; a.frames = frames_or_null; a.T = T;
+        a.splitk_ws = e->cur_splitk;  // one or two short clips: split-K over the taps (launch_gemm_split)
         Bracket br(e, s, K_POSCONV_SPLIT, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
         HIP_TRY(launch_gemm_split(a, s));
     }

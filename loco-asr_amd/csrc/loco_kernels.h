@@ -93,6 +93,11 @@ struct GemmSplitArgs {
     // range_slot[0..7] (see range_commit); null = not tracked.
     float* range_slot = nullptr;
     long sW2 = 0;                   // weight stride per z2 (0 = shared weights)
+    // z1 may itself be a pair (outer, inner), z1 = outer * z1_inner + inner: sA1 then strides the outer part, sA1i / sW1i the inner
+    // one (C still strides the combined z1).  Used by the split-K path of the grouped positional conv, whose batch dimensions
+    // (clip, group) are both taken: inner = K slice.
+    int z1_inner = 1;
+    long sA1i = 0, sW1i = 0;
     long sBias2 = 0;                // bias stride per z2
     const float* sin_table = nullptr;
     const int32_t* frames = nullptr;
