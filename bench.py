@@ -124,6 +124,23 @@ def workload_label(clip_seconds, batch):
             "random-init weights")
 
 
+def self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: start the N ranks as CHILD processes through
+    `python -m torch.distributed.run` (one rank per GPU over RCCL), relay their output -- rank 0 prints the JSON line --
+    and return the launcher's exit code.  Called before anything in this process has touched the GPU (importing torch does
+    not); the parent never initialises HIP, it only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def flops_per_clip(T: int) -> float:
     """Algorithmic FLOPs of one clip: 284.2 MFLOP*T + 36 864 FLOP*T^2."""
     return T * 284.2e6 + 36864.0 * T * T
@@ -151,14 +168,19 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree "
+                         f"(`python bench.py --gpus {args.gpus} ...` without a launcher starts the ranks itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the encoder has no CPU path")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py rank {rank}: --gpus {args.gpus} needs {world} GPUs on this node, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist

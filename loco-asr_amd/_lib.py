@@ -48,6 +48,10 @@ SIGNATURES = {
     "loco_forward_range": (C.c_int, [_vp, _i32, C.POINTER(_f), C.POINTER(_i32), C.c_char_p, _sz]),
     "loco_set_range_policy": (C.c_int, [_vp, C.c_int]),
     "loco_forward_checked": (C.c_int, [_vp, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, C.POINTER(_i32)]),
+    "loco_status_bytes": (_sz, []),
+    "loco_forward_async": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
+    "loco_status_check": (C.c_int, [_vp, C.c_char_p, _sz]),
+    "loco_status_range": (C.c_int, [_vp, _i32, C.POINTER(_f), C.POINTER(_i32), C.c_char_p, _sz]),
     "loco_resample_design": (C.c_int, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "loco_resample_length": (_i64, [_i64, _i32, _i32]),
     "loco_op_resample": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
@@ -56,6 +60,7 @@ SIGNATURES = {
     "loco_text_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "loco_text_max_positions": (C.c_int, [_vp]),
     "loco_forward_text": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "loco_precision_name": (C.c_char_p, [C.c_int]),
     "loco_set_precision": (C.c_int, [_vp, C.c_int]),
     "loco_get_precision": (C.c_int, [_vp]),
     "loco_set_streams": (C.c_int, [_vp, C.c_int]),
@@ -74,6 +79,7 @@ SIGNATURES = {
     "loco_op_split_f16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "loco_op_vt_column": (C.c_int32, [_i32]),
     "loco_gemm_splitk_bytes": (_sz, []),
+    "loco_debug_reload_gemm_knobs": (None, []),
     "loco_op_gemm_f16x3_splitk": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
                                             _vp, _sz, _vp]),
     "loco_op_gemm_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
@@ -96,6 +102,26 @@ SIGNATURES = {
 _lib = None
 
 
+def _check_foreign_build(path):
+    """LOCO_ASR_LIB loads a library that `make` did not build and check (tools/ab/, tools/conv0_race/ use their own flag sets):
+    inspect its gfx950 code for the banned packed-fp32 encoding (csrc/check_isa.py) before it can reach the product
+    path.  LOCO_ALLOW_BANNED_ISA=1 is for the reproducer of that very hazard only."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("loco_check_isa", os.path.join(_HERE, "csrc", "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    try:
+        _, _, bad = mod.check(path)
+    except (OSError, RuntimeError) as e:  # no llvm-objdump on this machine: say so, do not guess
+        import warnings
+        warnings.warn(f"LOCO_ASR_LIB={path}: could not inspect the code objects ({e})")
+        return
+    if bad and os.environ.get("LOCO_ALLOW_BANNED_ISA") != "1":
+        raise ImportError(f"LOCO_ASR_LIB={path}: {len(bad)} packed fp32 instructions cross-select their low lane (e.g. `{bad[0]}`): "
+                          "results are unreliable beside the attention kernel (DESIGN.md 5); set LOCO_ALLOW_BANNED_ISA=1 only to "
+                          "reproduce that hazard")
+
+
 def load():
     """Load libloco_asr.so once; raises (never falls back) when it is absent or stale."""
     global _lib
@@ -105,6 +131,8 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: the HIP library has not been built. Run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C {os.path.join(_HERE, 'csrc')}` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    if os.environ.get("LOCO_ASR_LIB"):
+        _check_foreign_build(LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         if os.environ.get("LOCO_ASR_LIB") and name.startswith("loco_op_") and not hasattr(lib, name):

@@ -106,8 +106,10 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
                                                           const float* __restrict__ w, const float* __restrict__ gn_b,
                                                           const float* __restrict__ mean, const float* __restrict__ scale,
                                                           float* __restrict__ out, _Float16* __restrict__ out_hi,
-                                                          _Float16* __restrict__ out_lo) {
+                                                          _Float16* __restrict__ out_lo, float* __restrict__ range_slot) {
     __shared__ float xs[kFramesPerBlock * 5 + 8];
+    const unsigned range_seen = SPLIT ? range_peek(range_slot) : 0u;  // read early: the load's latency hides under the taps
+    float amax = 0.f;
     const int b = blockIdx.y;
     const long t0 = (long)blockIdx.x * kFramesPerBlock;
     const int nt = (int)((T0 - t0 < kFramesPerBlock) ? (T0 - t0) : kFramesPerBlock);
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         float r0 = g_.x, r1 = g_.y;
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
             asm volatile("" : "+v"(r0), "+v"(r1));
+            amax = fmaxf(amax, fmaxf(fabsf(r0), fabsf(r1)));
             h2_t hi, lo;
             hi[0] = (_Float16)r0; hi[1] = (_Float16)r1;
             lo[0] = (_Float16)(r0 - (float)hi[0]); lo[1] = (_Float16)(r1 - (float)hi[1]);
@@ -155,10 +158,13 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
             *reinterpret_cast<float2*>(out + obase + (long)t * kConvDim) = make_float2(r0, r1);
         }
     }
+    // range tracking of the planes written (loco_kernels.h): max|x| of this workgroup's 64 frames x 512 channels, one atomic per
+    // workgroup and only when the stage's word does not cover it yet
+    if (SPLIT) range_commit_block(range_slot, amax, range_seen);
 }
 
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
-                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi, void* out_lo) {
+                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi, void* out_lo, float* range_slot) {
     const long T0 = conv_out_len(L, 10, 5);
     if (B <= 0 || T0 <= 0) return hipErrorInvalidValue;
     double* partial = reinterpret_cast<double*>(scratch);
@@ -170,10 +176,10 @@ hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w,
     const unsigned nblk = (unsigned)((T0 + kFramesPerBlock - 1) / kFramesPerBlock);
     if (out_hi)
         hipLaunchKernelGGL(conv0_apply_kernel<true>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
-                           (_Float16*)out_hi, (_Float16*)out_lo);
+                           (_Float16*)out_hi, (_Float16*)out_lo, range_slot);
     else
         hipLaunchKernelGGL(conv0_apply_kernel<false>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
-                           (_Float16*)nullptr, (_Float16*)nullptr);
+                           (_Float16*)nullptr, (_Float16*)nullptr, (float*)nullptr);
     return hipGetLastError();
 }
 

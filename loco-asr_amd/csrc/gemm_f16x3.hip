@@ -730,6 +730,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_posconv_kernel(GemmSplitArg
     }
 }
 
+// A/B knobs of the tile dispatch (tools/gemm_split_bench.py, tools/gemm_stamps.py, tests/test_gpu_ops.py): LOCO_GEMM_TILE=<1..8>
+// forces one tile form, LOCO_GEMM_TILE_NARROW=<n> replaces the 256x128 form, LOCO_GEMM_NOPERSIST / _NOCOLGROUP / _NO192 switch
+// one mechanism off.  They are read from the environment ONCE (first launch) -- no getenv on the launch path, which runs ~67 times
+// per forward and possibly on several host threads -- and again only when a tool asks for it (loco_debug_reload_gemm_knobs).
+struct GemmKnobs {
+    int tile = 0, narrow = 0;
+    bool nopersist = false, nocolgroup = false, no192 = false;
+};
+static GemmKnobs read_gemm_knobs() {
+    GemmKnobs k;
+    const char* v;
+    if ((v = getenv("LOCO_GEMM_TILE"))) k.tile = atoi(v);
+    if ((v = getenv("LOCO_GEMM_TILE_NARROW"))) k.narrow = atoi(v);
+    k.nopersist = getenv("LOCO_GEMM_NOPERSIST") != nullptr;
+    k.nocolgroup = getenv("LOCO_GEMM_NOCOLGROUP") != nullptr;
+    k.no192 = getenv("LOCO_GEMM_NO192") != nullptr;
+    return k;
+}
+static GemmKnobs& gemm_knobs() {
+    static GemmKnobs k = read_gemm_knobs();
+    return k;
+}
+void reload_gemm_knobs() { gemm_knobs() = read_gemm_knobs(); }
+
 // One tile form for every epilogue / output kind: WM x WN waves of 64 x 64, AST / WST ring slots, WPS as in the kernel template.
 template <int WM, int WN, int AST, int WST, int WPS, int TERMS = 3>
 static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
@@ -740,17 +764,17 @@ static hipError_t launch_tile(const GemmSplitArgs& a, hipStream_t s) {
     const bool sp = a.Chi != nullptr;
     // Persistent form: one workgroup per CU slot (256 CUs x WPS-per-CU), each walking its XCD's run of tiles, when there are more
     // tiles than slots and the k-loop is at least as long as the A ring (the DMA stream looks AST k-tiles ahead, into the next
-    // output tile at most).  LOCO_GEMM_NOPERSIST=1 (read per call) launches one workgroup per tile, for A/B runs and the stamp tool.
+    // output tile at most).  LOCO_GEMM_NOPERSIST=1 (gemm_knobs) launches one workgroup per tile, for A/B runs and the stamp tool.
     // The forms with 12 waves or fewer have the registers for it (168+ per wave); the 16-wave form (128) does not and runs one tile per
     // workgroup (it gained 0-1 % from it; the 192x256 form gains 3-7 %, the table GEMM on the two-per-CU 128x128 form 12 %).
     constexpr bool kPersist = WM * WN <= 12;
     constexpr int slots = 256 * (WPS ? (4 * WPS) / (WM * WN) : 1);
-    const bool persist = kPersist && nb > slots && a.K / SBK >= AST && !getenv("LOCO_GEMM_NOPERSIST");
+    const bool persist = kPersist && nb > slots && a.K / SBK >= AST && !gemm_knobs().nopersist;
     const unsigned grid = persist ? (unsigned)slots : (unsigned)nb;
     const int wg_step = persist ? slots / 8 : 0;
     // column tiles per group of the in-XCD tile order (see the kernel's decode): the divisor-like value nearest sqrt(32)
     const int ngroups = (tn + 5) / 6;
-    const int col_group = getenv("LOCO_GEMM_NOCOLGROUP") ? tn : (tn + ngroups - 1) / ngroups;
+    const int col_group = gemm_knobs().nocolgroup ? tn : (tn + ngroups - 1) / ngroups;
 #define TILE_LAUNCH(EPI)                                                                                                              \
     if (sp) hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, true, WM, WN, AST, WST, 4, WPS, TERMS, kPersist>), dim3(grid), dim3(64 * WM * WN), 0, \
                                s, a, tm, tn, (int)nb, wg_step, col_group);                                                            \
@@ -870,10 +894,9 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             return hipGetLastError();
         }
     }
-    // Tile choice (tools/gemm_split_bench.py, MI355X).  LOCO_GEMM_TILE=<1..5> forces one form; it is read on every call so
-    // that a bench can A/B the forms inside one process (same device, same clocks).
-    const char* forced = getenv("LOCO_GEMM_TILE");
-    int tile = forced ? atoi(forced) : 0;
+    // Tile choice (tools/gemm_split_bench.py, MI355X).  LOCO_GEMM_TILE=<1..8> forces one form (gemm_knobs: a bench A/Bs the forms
+    // inside one process -- same device, same clocks -- by changing the environment and calling loco_debug_reload_gemm_knobs).
+    int tile = gemm_knobs().tile;
     if (tile == 0) {
         if (a.M >= 1024) {
             // Measured on MI355X (tools/gemm_split_bench.py --tiles=..., and bench.py with LOCO_GEMM_TILE_NARROW in the two-stream
@@ -886,7 +909,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
             const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
             if (a.K <= 128) tile = 4;
             else tile = (a.N % 256 == 0 && t256 >= 256) ? 1 : 2;
-            if (tile == 1 && !a.co_scheduled && !getenv("LOCO_GEMM_NO192")) {
+            if (tile == 1 && !a.co_scheduled && !gemm_knobs().no192) {
                 // Whole rounds of 256 workgroups are what a launch costs: 47 968 x 768 is 564 tiles of 256x256 = 2.2 rounds, paid as 3,
                 // but 750 tiles of 192x256 (12 waves, 112 KiB ring) = 2.93 rounds of a tile 3/4 the size: out-proj -15 %, FFN2 -12 %.
                 // Per FLOP the 192-row form is ~10 % behind (more L2 -> LDS bytes, 3 waves per SIMD), so it is chosen only when its
@@ -896,8 +919,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
                 const long c256 = ((t256 + 255) / 256) * 256 * 10, c192 = ((t192 + 255) / 256) * 192 * 11;
                 if (c192 < c256) tile = 6;
             }
-            const char* narrow = getenv("LOCO_GEMM_TILE_NARROW");  // A/B knob for the GEMMs that would take the 256x128 form
-            if (tile == 2 && narrow) tile = atoi(narrow);
+            if (tile == 2 && gemm_knobs().narrow) tile = gemm_knobs().narrow;  // A/B knob for the GEMMs that would take the 256x128 form
         } else {
             tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
         }

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -82,6 +83,32 @@ struct ProfRec {
     double flops, bytes;
 };
 
+// Status block of ONE forward (include/loco_asr.h, loco_status_bytes): host memory, caller-owned for loco_forward_async, the
+// handle's own pinned block for loco_forward.  The host part is filled while the forward is enqueued; `words` is the target of the
+// device-to-host copy that follows the forward on its stream.
+constexpr uint32_t kStatusMagic = 0x53434f4cu;  // "LOCS"
+struct StatusBlock {
+    uint32_t magic;
+    int32_t precision;                        // arithmetic mode of the forward this block describes
+    int32_t used;                             // stages filled
+    int32_t layer[kRangeMaxStages];
+    const char* names[kRangeMaxStages];       // static strings of this library
+    char msg[384];                            // non-empty: a range verdict known on the host (weights outside the planes' range)
+    float words[kRangeMaxStages * kRangeShards];
+};
+// device side of the same: the first bytes of every workspace
+constexpr size_t kStatusDevBytes = (sizeof(float) * kRangeMaxStages * kRangeShards + 255) & ~size_t(255);
+
+// Per-call state of one loco_forward*: everything the enqueue mutates lives here, not in the handle, so that forwards of one
+// handle may be enqueued from several host threads and be in flight together (different streams, workspaces and status blocks).
+struct Call {
+    int precision = 1;
+    float* splitk = nullptr;     // split-K workspace of the (half-)batch being enqueued (null for large problems)
+    bool dual = false;           // inside the two half-batch schedule (GemmSplitArgs::co_scheduled)
+    float* range_dev = nullptr;  // [kRangeMaxStages][kRangeShards] in the workspace, zeroed at the start of the forward
+    StatusBlock* st = nullptr;
+};
+
 }  // namespace
 
 struct loco_encoder {
@@ -111,23 +138,18 @@ struct loco_encoder {
     float* text_pe = nullptr;     // [text_pe_rows, 768]
     int text_pe_rows = 0;
     bool speech_ready = false;    // set by loco_finalize_weights when the speech prenet weights were supplied
-    float* cur_splitk = nullptr;  // split-K workspace of the forward being enqueued (null for large problems)
-    // concurrency: a batch may run as two half-batches on two streams (loco_set_streams)
+    // concurrency inside one forward: a batch may run as two half-batches on two streams (loco_set_streams).  The side stream and
+    // its events are created on first use under side_mu; forwards in flight together serialise their second halves on it.
     int streams = 2;
     hipStream_t side = nullptr;
-    bool dual_active = false;  // inside the two half-batch schedule (GemmSplitArgs::co_scheduled)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    // range tracking of the fp16-plane activations (loco_kernels.h, range_commit): one status word x 8 shards per stage
-    float* range_dev = nullptr;   // [kRangeMaxStages][kRangeShards], zeroed at the start of every forward
-    float* range_host = nullptr;  // pinned copy made at the end of every forward (valid once the stream has got there)
+    std::mutex side_mu;
+    // range tracking of the fp16-plane activations (loco_kernels.h, range_commit): one status word x 8 shards per stage, in the
+    // workspace of each forward; `own` is the status block of the forwards enqueued through loco_forward (pinned host memory)
+    StatusBlock* own = nullptr;
     float* absmax_dev = nullptr;  // one float, weight preparation
-    int range_used = 0;           // stages the last forward filled
-    const char* range_names[kRangeMaxStages] = {nullptr};
-    int range_layer[kRangeMaxStages] = {0};
     int range_policy = 1;         // loco_forward_checked: 1 = re-run out-of-range batches on the exact-fp32 kernels, 0 = report
-    std::string range_static;     // non-empty: a weight-determined plane tensor (LayerNorm / GroupNorm output) leaves the range
-    float gn_gmax = 0.f, gn_bmax = 0.f;  // conv0 GroupNorm affine: its bound depends on the frames per clip, checked per forward
-    std::string range_forward;    // the same, for the part that depends on the input length (conv0)
+    std::string range_static;     // non-empty: a weight-determined plane tensor (a LayerNorm output) leaves the range
     // profiling
     bool profiling = false;
     std::vector<ProfRec> recs;
@@ -304,7 +326,7 @@ int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const
 }
 
 // split-precision GEMM: A and W as fp16 hi/lo planes; output fp32 (C) or planes (Chi/Clo)
-int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
+int run_gemm_split(loco_encoder* e, const Call& c, hipStream_t s, const _Float16* Ahi, const _Float16* Alo, long lda, const SplitW& Wt, long ldw,
                    const float* bias, const float* R, long ldr, float* C, _Float16* Chi, _Float16* Clo, long ldc, int M, int N, int K,
                    int epi, int nb1 = 1, long sA1 = 0, long sC1 = 0, int nb2 = 1, long sA2 = 0, long sC2 = 0,
                    const GemmSplitArgs* scatter = nullptr, const _Float16* Rhi = nullptr, const _Float16* Rlo = nullptr,
@@ -314,14 +336,14 @@ int run_gemm_split(loco_encoder* e, hipStream_t s, const _Float16* Ahi, const _F
     a.Rlo = Rlo;
     a.out_scale = Wt.inv_scale;
     a.range_slot = range_slot;
-    a.co_scheduled = e->dual_active;
+    a.co_scheduled = c.dual;
     a.ktaps = ktaps;
-    a.terms = (e->precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
+    a.terms = (c.precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
         a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
         a.T = scatter->T; a.Tp = scatter->Tp;
     }
-    a.splitk_ws = e->cur_splitk;
+    a.splitk_ws = c.splitk;
     const double nb = (double)nb1 * nb2;
     const double flops = 2.0 * M * (double)N * K * nb;
     const double bytes = 4.0 * (nb * ((double)M * K + (double)M * N * (epi == kEpiResidual ? 2 : 1)) + (double)N * K);
@@ -366,8 +388,7 @@ constexpr float kRangeHi = 65504.0f;   // fp16 maximum: hi = fp16(x) is inf from
 constexpr float kRangeLo = 0.015625f;  // 2^-6: a plane tensor whose LARGEST element is below this has lost fp32-class accuracy
 
 // Plane tensors whose range follows from the weights: y = x_hat * gamma + beta with sum(x_hat^2) <= D gives
-// |y| <= sqrt(D) max|gamma| + max|beta| (LayerNorm over D channels; conv0's GroupNorm over D = frames of the clip, GELU only
-// shrinks it), and a unit-variance x_hat puts the tensor's largest element near max(max|gamma|, max|beta|).  The attention
+// |y| <= sqrt(D) max|gamma| + max|beta| (LayerNorm over D channels), and a unit-variance x_hat puts the tensor's largest element near max(max|gamma|, max|beta|).  The attention
 // context is a convex combination of V rows, tracked with q|k|v.  Checked once per weight load; nothing is measured at run time.
 int static_range_check(loco_encoder* e, const std::string& ln_prefix, int dim, hipStream_t s) {
     float g = 0.f, b = 0.f;
@@ -524,7 +545,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
 // ---- precision 1: every contraction (conv layers 1-6, feature projection, positional conv, QKV / out / FFN projections, the
 // Qp table, QK^T and PV) on the fp16 x3 split MFMA; every producer writes the fp16 hi/lo planes its consumer needs, so no
 // separate conversion pass exists.  conv0 (10 taps, VALU), residuals, GroupNorm / LayerNorm statistics and softmax stay fp32.
-int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
+int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, float* out, float* const* hidden_states, const Bufs& bf,
                   hipStream_t s, bool skip_prenet = false) {
     const int B = p.B;
     const long L = p.L;
@@ -557,10 +578,10 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     // share the words (a maximum does not care who contributes)
     int nslot = 0;
     auto slot = [&](const char* name, int layer = -1) -> float* {
-        if (!e->range_dev || nslot >= kRangeMaxStages) return nullptr;
-        e->range_names[nslot] = name;
-        e->range_layer[nslot] = layer;
-        return e->range_dev + (size_t)kRangeShards * nslot++;
+        if (!c.range_dev || !c.st || nslot >= kRangeMaxStages) return nullptr;
+        c.st->names[nslot] = name;
+        c.st->layer[nslot] = layer;
+        return c.range_dev + (size_t)kRangeShards * nslot++;
     };
     static const char* const kConvNames[7] = {"feature_encoder.conv_layers.0 (GroupNorm + GELU)", "feature_encoder.conv_layers.1",
                                               "feature_encoder.conv_layers.2", "feature_encoder.conv_layers.3",
@@ -576,7 +597,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
         HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
                                      W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), nullptr, bf.c0scratch,
-                                     e->cfg.ln_eps, s, ihi, ilo));
+                                     e->cfg.ln_eps, s, ihi, ilo, slot(kConvNames[0])));
     }
     float* cin = bf.bufA;
     float* cout = bf.bufB;
@@ -585,7 +606,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         planes(cin, (size_t)B * Tin * kConvDim, ihi, ilo);
         planes(cout, (size_t)B * Tout * kConvDim, ohi, olo);
         const bool last = i == 6;
-        rc = run_gemm_split(e, s, ihi, ilo, (long)kConvS[i] * kConvDim, e->conv_s[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
+        rc = run_gemm_split(e, c, s, ihi, ilo, (long)kConvS[i] * kConvDim, e->conv_s[i], (long)kConvK[i] * kConvDim, nullptr, nullptr, 0,
                             last ? cout : nullptr, last ? nullptr : ohi, last ? nullptr : olo, kConvDim, (int)Tout, kConvDim,
                             kConvK[i] * kConvDim, kEpiGelu, B, Tin * kConvDim, Tout * kConvDim, 1, 0, 0, nullptr, nullptr, nullptr,
                             last ? nullptr : slot(kConvNames[i]), K_GEMM_SPLIT, kConvK[i]);
@@ -602,7 +623,7 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     if ((rc = run_ln(e, s, feats, W(e, pn + "feature_projection.layer_norm.weight"), W(e, pn + "feature_projection.layer_norm.bias"),
                      nullptr, M, kConvDim, ohi, olo)))
         return rc;
-    if ((rc = run_gemm_split(e, s, ohi, olo, kConvDim, e->proj_s, kConvDim, W(e, pn + "feature_projection.projection.bias"), nullptr, 0,
+    if ((rc = run_gemm_split(e, c, s, ohi, olo, kConvDim, e->proj_s, kConvDim, W(e, pn + "feature_projection.projection.bias"), nullptr, 0,
                              x1, nullptr, nullptr, kHidden, (int)M, kHidden, kConvDim, kEpiNone)))
         return rc;
     if (e->tap_proj && (rc = run_copy(e, s, e->tap_proj, x1, (size_t)M * kHidden))) return rc;
@@ -629,9 +650,9 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         a.sW2 = (long)kPosCg * kPosK * kPosCg; a.sBias2 = kPosCg;
         a.epilogue = kEpiPosConv;
         a.out_scale = e->posg_s.inv_scale;
-        a.terms = e->precision == 2 ? 2 : 3;
+        a.terms = c.precision == 2 ? 2 : 3;
         a.sin_table = e->sin_tab; a.frames = frames_or_null; a.T = T;
-        a.splitk_ws = e->cur_splitk;  // one or two short clips: split-K over the taps (launch_gemm_split)
+        a.splitk_ws = c.splitk;  // one or two short clips: split-K over the taps (launch_gemm_split)
         Bracket br(e, s, K_POSCONV_SPLIT, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
         HIP_TRY(launch_gemm_split(a, s));
     }
@@ -655,12 +676,12 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
         const std::string b = we + "layers." + std::to_string(l) + ".";
         const LayerW& lw = e->layers[l];
         // fused q|k|v projection -> q, k as fp16 hi/lo planes, v transposed per head (the layouts attention_f16x3 reads)
-        if ((rc = run_gemm_split(e, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, nullptr, qshi, qslo, kHidden, (int)M,
+        if ((rc = run_gemm_split(e, c, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, nullptr, qshi, qslo, kHidden, (int)M,
                                  kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat, nullptr, nullptr,
                                  slot("attention q|k|v projections", l))))
             return rc;
         // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320]
-        if ((rc = run_gemm_split(e, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
+        if ((rc = run_gemm_split(e, c, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
                                  kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN,
                                  nullptr, nullptr, nullptr, nullptr, K_QP)))
             return rc;
@@ -670,15 +691,15 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
             HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
                                            Tp, s));
         }
-        if ((rc = run_gemm_split(e, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), nullptr, kHidden, tmp, nullptr,
+        if ((rc = run_gemm_split(e, c, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), nullptr, kHidden, tmp, nullptr,
                                  nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x0hi, x0lo)))
             return rc;
         if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), nullptr, M, kHidden, x1hi, x1lo))) return rc;
-        if ((rc = run_gemm_split(e, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
+        if ((rc = run_gemm_split(e, c, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
                                  nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu, 1, 0, 0, 1, 0, 0, nullptr, nullptr,
                                  nullptr, slot("feed_forward intermediate (GELU)", l))))
             return rc;
-        if ((rc = run_gemm_split(e, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), nullptr, kHidden,
+        if ((rc = run_gemm_split(e, c, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), nullptr, kHidden,
                                  tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x1hi,
                                  x1lo)))
             return rc;
@@ -689,20 +710,24 @@ int forward_f16x3(loco_encoder* e, const Plan& p, const float* wav, float* out, 
     }
     if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
     if (hidden_states && hidden_states[nl] && (rc = run_copy(e, s, hidden_states[nl], out, (size_t)M * kHidden))) return rc;
-    e->range_used = nslot;
+    if (c.st) c.st->used = nslot;
     return LOCO_OK;
 }
 
 // The status words travel to pinned host memory behind the forward, on its stream: readable once the stream has got there.
-int range_begin(loco_encoder* e, hipStream_t s) {
-    e->range_used = 0;
-    e->range_forward.clear();
-    if (e->range_dev) HIP_TRY(hipMemsetAsync(e->range_dev, 0, sizeof(float) * kRangeMaxStages * kRangeShards, s));
+int range_begin(loco_encoder* e, Call& c, hipStream_t s) {
+    StatusBlock* st = c.st;
+    st->magic = kStatusMagic;
+    st->precision = c.precision;
+    st->used = 0;
+    st->msg[0] = 0;
+    if (c.precision >= 1 && !e->range_static.empty()) snprintf(st->msg, sizeof st->msg, "%s", e->range_static.c_str());
+    if (c.precision >= 1) HIP_TRY(hipMemsetAsync(c.range_dev, 0, sizeof(float) * kRangeMaxStages * kRangeShards, s));
     return LOCO_OK;
 }
-int range_end(loco_encoder* e, hipStream_t s) {
-    if (e->range_dev && e->range_used > 0)
-        HIP_TRY(hipMemcpyAsync(e->range_host, e->range_dev, sizeof(float) * kRangeShards * e->range_used, hipMemcpyDeviceToHost, s));
+int range_end(const Call& c, hipStream_t s) {
+    if (c.precision >= 1 && c.st->used > 0)
+        HIP_TRY(hipMemcpyAsync(c.st->words, c.range_dev, sizeof(float) * kRangeShards * c.st->used, hipMemcpyDeviceToHost, s));
     return LOCO_OK;
 }
 
@@ -752,16 +777,15 @@ loco_encoder* loco_create(const loco_config* cfg) {
     loco_encoder* e = new loco_encoder();
     e->cfg = c;
     e->device = dev;
-    if (hipMalloc(&e->range_dev, sizeof(float) * kRangeMaxStages * kRangeShards) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&e->range_host), sizeof(float) * kRangeMaxStages * kRangeShards, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void**>(&e->own), sizeof(StatusBlock), hipHostMallocDefault) != hipSuccess ||
         hipMalloc(&e->absmax_dev, sizeof(float)) != hipSuccess) {
-        fail(LOCO_E_HIP, "loco_create: could not allocate the range-status words");
-        (void)hipFree(e->range_dev);
-        if (e->range_host) (void)hipHostFree(e->range_host);
+        fail(LOCO_E_HIP, "loco_create: could not allocate the range-status block");
+        if (e->own) (void)hipHostFree(e->own);
         delete e;
         return nullptr;
     }
-    memset(e->range_host, 0, sizeof(float) * kRangeMaxStages * kRangeShards);
+    memset(e->own, 0, sizeof(StatusBlock));
+    e->own->magic = kStatusMagic;
     e->layers.resize(c.layers);
     build_expected(e);
     for (int i = 0; i < K_COUNT; ++i) {
@@ -792,9 +816,8 @@ void loco_destroy(loco_encoder* e) {
         free_split(l.s1);
         free_split(l.s2);
     }
-    (void)hipFree(e->range_dev);
     (void)hipFree(e->absmax_dev);
-    if (e->range_host) (void)hipHostFree(e->range_host);
+    if (e->own) (void)hipHostFree(e->own);
     (void)hipFree(e->sin_tab);
     (void)hipFree(e->text_embed);
     (void)hipFree(e->text_alpha);
@@ -976,13 +999,10 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
         if (rc) return rc;
     }
     // weight-determined activation ranges of precision mode f16x3 (static_range_check above)
+    // (conv0's GroupNorm + GELU output is not among them: its bound sqrt(frames per clip) * max|gamma| + max|beta| says nothing
+    // useful for 10-minute clips -- 1385 * max|gamma| -- so conv0_apply_kernel folds max|x| of what it writes like the GEMMs do)
     e->range_static.clear();
-    e->gn_gmax = e->gn_bmax = 0.f;
-    if (speech) {
-        rc = absmax_host(e, W(e, p + "feature_encoder.conv_layers.0.layer_norm.weight"), kConvDim, s, e->gn_gmax);
-        if (!rc) rc = absmax_host(e, W(e, p + "feature_encoder.conv_layers.0.layer_norm.bias"), kConvDim, s, e->gn_bmax);
-        if (!rc) rc = static_range_check(e, p + "feature_projection.layer_norm.", kConvDim, s);
-    }
+    if (speech) rc = static_range_check(e, p + "feature_projection.layer_norm.", kConvDim, s);
     if (!rc) rc = static_range_check(e, w + "layer_norm.", kHidden, s);
     for (int l = 0; l < e->cfg.layers && !rc; ++l) {
         const std::string b = w + "layers." + std::to_string(l) + ".";
@@ -1020,8 +1040,8 @@ bool split_batch(const loco_encoder* e, int B, long L, Plan& p0, Plan& p1) {
 size_t loco_workspace_bytes(const loco_encoder* e, int32_t B, int64_t L) {
     Plan p, p0, p1;
     if (!e || !make_plan(e, B, L, p)) return 0;
-    if (split_batch(e, B, L, p0, p1)) return std::max(p.total, p0.total + p1.total);
-    return p.total;
+    if (split_batch(e, B, L, p0, p1)) return kStatusDevBytes + std::max(p.total, p0.total + p1.total);
+    return kStatusDevBytes + p.total;
 }
 
 int loco_set_streams(loco_encoder* e, int n) {
@@ -1030,8 +1050,13 @@ int loco_set_streams(loco_encoder* e, int n) {
     return LOCO_OK;
 }
 
+const char* loco_precision_name(int mode) {
+    static const char* const kNames[] = {"f32", "f16x3", "f16x2"};
+    return (mode >= 0 && mode < 3) ? kNames[mode] : nullptr;
+}
+
 int loco_set_precision(loco_encoder* e, int mode) {
-    if (!e || mode < 0 || mode > 2) return fail(LOCO_E_INVALID, "loco_set_precision: mode must be 0 (f32), 1 (f16x3) or 2 (f16x2)");
+    if (!e || !loco_precision_name(mode)) return fail(LOCO_E_INVALID, "loco_set_precision: mode must be 0 (f32), 1 (f16x3) or 2 (f16x2)");
     e->precision = mode;
     return LOCO_OK;
 }
@@ -1047,7 +1072,7 @@ int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection,
 }
 
 namespace {
-int forward_one(loco_encoder* e, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
+int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
                 float* const* hidden_states, char* ws, hipStream_t s) {
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* bufA = reinterpret_cast<float*>(ws + p.off_a);
@@ -1069,14 +1094,16 @@ int forward_one(loco_encoder* e, const Plan& p, const float* wav, const int32_t*
 
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
-    e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
-    return e->precision >= 1 ? forward_f16x3(e, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
+    c.splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
+    return c.precision >= 1 ? forward_f16x3(e, c, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
 }
-}  // namespace
 
-int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
+// One forward in arithmetic mode `precision`, its range words in the first bytes of the workspace, its status in `st`.  Nothing
+// the enqueue mutates is shared between calls except the lazily created side stream (side_mu), the profiling records (profiling
+// is a single-caller diagnostic mode) and the sinusoid table when a clip longer than any before makes it grow.
+int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
                  int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!e || !wav || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward: null argument");
+    if (!e || !wav || !out || !workspace || !st) return fail(LOCO_E_INVALID, "loco_forward: null argument");
     if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
     if (!e->speech_ready) return fail(LOCO_E_STATE, "loco_forward: this encoder was loaded without the speech prenet weights");
     Plan p, p0, p1;
@@ -1086,7 +1113,7 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     if (p.M > 0x7fffffffL / 8) return fail(LOCO_E_INVALID, "loco_forward: B*T = %ld frames is too large", p.M);
     // per-kernel timing, hidden-state and tap outputs keep the single in-order pass
     const bool dual = !e->profiling && !hidden_states && !e->tap_conv && !e->tap_proj && !e->tap_prenet && split_batch(e, B, L, p0, p1);
-    const size_t need = dual ? p0.total + p1.total : p.total;
+    const size_t need = kStatusDevBytes + (dual ? p0.total + p1.total : p.total);
     if (workspace_bytes < need)
         return fail(LOCO_E_WORKSPACE, "loco_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(wav) & 3))
@@ -1094,25 +1121,20 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sin_rows(e, (int)p.T + 2, s);
     if (rc) return rc;
-    char* ws = reinterpret_cast<char*>(workspace);
-    if ((rc = range_begin(e, s))) return rc;
-    if (e->precision >= 1) {  // conv0's GroupNorm + GELU output: bounded by sqrt(frames) max|gamma| + max|beta| (static_range_check)
-        const float hi = sqrtf((float)p.Tc[0]) * e->gn_gmax + e->gn_bmax, lo = fmaxf(e->gn_gmax, e->gn_bmax);
-        if (!(hi < kRangeHi) || lo < kRangeLo) {
-            char msg[320];
-            snprintf(msg, sizeof msg, "activation range: the output of 'prenet.feature_encoder.conv_layers.0' (GroupNorm max|weight| = %.6g, "
-                     "max|bias| = %.6g, %ld frames per clip) is %s the range precision mode f16x3 represents to fp32 class (%g <= max|x| < %g)",
-                     (double)e->gn_gmax, (double)e->gn_bmax, p.Tc[0], !(hi < kRangeHi) ? "not bounded inside" : "below", (double)kRangeLo,
-                     (double)kRangeHi);
-            e->range_forward = msg;
-        }
-    }
+    Call c;
+    c.precision = precision;
+    c.st = st;
+    c.range_dev = reinterpret_cast<float*>(workspace);
+    char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
+    if ((rc = range_begin(e, c, s))) return rc;
     if (!dual) {
-        rc = forward_one(e, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
+        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
         if (rc) return rc;
-        return range_end(e, s);
+        return range_end(c, s);
     }
 
+    // The side stream is one per handle: forwards in flight together take turns on it (the lock covers the enqueue only).
+    std::lock_guard<std::mutex> lock(e->side_mu);
     if (!e->side) {
         HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -1123,14 +1145,14 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
     HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
     // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
     // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
-    e->dual_active = true;
-    rc = forward_one(e, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
+    c.dual = true;
+    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
     int rc1 = LOCO_OK;
     std::string first_error;
     if (rc) first_error = g_err;
-    else rc1 = forward_one(e, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
+    else rc1 = forward_one(e, c, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
                            out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
-    e->dual_active = false;
+    c.dual = false;
     if (!rc && rc1) first_error = g_err;
     const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves
     const hipError_t j2 = j1 == hipSuccess ? hipStreamWaitEvent(s, e->ev_join, 0) : j1;
@@ -1143,28 +1165,34 @@ int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t
         g_err = first_error;
         return rc ? rc : rc1;
     }
-    return range_end(e, s);
+    return range_end(c, s);
 }
 
-// ---- range status of the last forward (include/loco_asr.h) -----------------------------------------------------------------
-int loco_forward_status(loco_encoder* e, char* buf, size_t buflen) {
-    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+const StatusBlock* as_status(const void* status) {
+    const StatusBlock* st = reinterpret_cast<const StatusBlock*>(status);
+    return (st && st->magic == kStatusMagic) ? st : nullptr;
+}
+
+float stage_amax(const StatusBlock* st, int i) {
+    float amax = 0.f;
+    for (int k = 0; k < kRangeShards; ++k) amax = fmaxf(amax, st->words[(size_t)i * kRangeShards + k]);
+    return amax;
+}
+
+int status_check(const StatusBlock* st, char* buf, size_t buflen) {
     if (buf && buflen) buf[0] = 0;
-    if (e->precision >= 1) {
-        const std::string& m = !e->range_static.empty() ? e->range_static : e->range_forward;
-        if (!m.empty()) {
-            if (buf && buflen) snprintf(buf, buflen, "%s", m.c_str());
-            return fail(LOCO_E_RANGE, "%s; use the exact-fp32 kernels for this model (loco_set_precision(enc, 0) / loco_forward_checked)", m.c_str());
-        }
+    if (st->precision == 0) return LOCO_OK;  // the exact-fp32 mode stores no fp16 planes
+    if (st->msg[0]) {
+        if (buf && buflen) snprintf(buf, buflen, "%s", st->msg);
+        return fail(LOCO_E_RANGE, "%s; use the exact-fp32 kernels for this model (loco_set_precision(enc, 0) / loco_forward_checked)", st->msg);
     }
-    for (int i = 0; i < e->range_used; ++i) {
-        float amax = 0.f;
-        for (int k = 0; k < kRangeShards; ++k) amax = fmaxf(amax, e->range_host[(size_t)i * kRangeShards + k]);
+    for (int i = 0; i < st->used; ++i) {
+        const float amax = stage_amax(st, i);
         const bool over = !(amax < kRangeHi), under = amax < kRangeLo;
         if (!over && !under) continue;
         char where[160];
-        if (e->range_layer[i] >= 0) snprintf(where, sizeof where, "wrapped_encoder.layers.%d %s", e->range_layer[i], e->range_names[i]);
-        else snprintf(where, sizeof where, "%s", e->range_names[i]);
+        if (st->layer[i] >= 0) snprintf(where, sizeof where, "wrapped_encoder.layers.%d %s", st->layer[i], st->names[i]);
+        else snprintf(where, sizeof where, "%s", st->names[i]);
         char msg[400];
         snprintf(msg, sizeof msg,
                  "activation range: max|x| = %.6g of '%s' is %s the range precision mode f16x3 represents to fp32 class "
@@ -1176,15 +1204,60 @@ int loco_forward_status(loco_encoder* e, char* buf, size_t buflen) {
     return LOCO_OK;
 }
 
+int status_range(const StatusBlock* st, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen) {
+    if (stage < 0 || stage >= st->used) return st->used;  // not an error: lets a caller enumerate 0 .. n-1
+    if (amax) *amax = stage_amax(st, stage);
+    if (layer) *layer = st->layer[stage];
+    if (name && namelen) snprintf(name, namelen, "%s", st->names[stage]);
+    return st->used;
+}
+}  // namespace
+
+int loco_forward(loco_encoder* e, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
+                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e) return fail(LOCO_E_INVALID, "loco_forward: null argument");
+    return forward_impl(e, e->precision, e->own, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
+}
+
+// ---- forwards in flight: one status block per forward (include/loco_asr.h) ---------------------------------------------------
+size_t loco_status_bytes(void) { return sizeof(StatusBlock); }
+
+int loco_forward_async(loco_encoder* e, int precision, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
+                       int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream,
+                       void* status) {
+    if (!e || !status) return fail(LOCO_E_INVALID, "loco_forward_async: null argument");
+    if (precision != -1 && !loco_precision_name(precision))
+        return fail(LOCO_E_INVALID, "loco_forward_async: precision must be -1 (the handle's mode) or one of " LOCO_PRECISION_MODES);
+    if (reinterpret_cast<uintptr_t>(status) & 7) return fail(LOCO_E_INVALID, "loco_forward_async: the status block must be 8-byte aligned");
+    StatusBlock* st = reinterpret_cast<StatusBlock*>(status);
+    st->magic = 0;  // not a valid status until the enqueue has succeeded
+    const int rc = forward_impl(e, precision < 0 ? e->precision : precision, st, wav, mask, B, L, out, out_frames, hidden_states, workspace,
+                                workspace_bytes, stream);
+    if (rc) st->magic = 0;
+    return rc;
+}
+
+int loco_status_check(const void* status, char* buf, size_t buflen) {
+    const StatusBlock* st = as_status(status);
+    if (!st) return fail(LOCO_E_INVALID, "loco_status_check: not a status block filled by loco_forward_async");
+    return status_check(st, buf, buflen);
+}
+
+int loco_status_range(const void* status, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen) {
+    const StatusBlock* st = as_status(status);
+    if (!st) return fail(LOCO_E_INVALID, "loco_status_range: not a status block filled by loco_forward_async");
+    return status_range(st, stage, amax, layer, name, namelen);
+}
+
+// ---- range status of the last forward enqueued through loco_forward / loco_forward_text (include/loco_asr.h) ------------------
+int loco_forward_status(loco_encoder* e, char* buf, size_t buflen) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    return status_check(e->own, buf, buflen);
+}
+
 int loco_forward_range(const loco_encoder* e, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen) {
     if (!e) return fail(LOCO_E_INVALID, "null encoder");
-    if (stage < 0 || stage >= e->range_used) return e->range_used;  // not an error: lets a caller enumerate 0 .. n-1
-    float m = 0.f;
-    for (int k = 0; k < kRangeShards; ++k) m = fmaxf(m, e->range_host[(size_t)stage * kRangeShards + k]);
-    if (amax) *amax = m;
-    if (layer) *layer = e->range_layer[stage];
-    if (name && namelen) snprintf(name, namelen, "%s", e->range_names[stage]);
-    return e->range_used;
+    return status_range(e->own, stage, amax, layer, name, namelen);
 }
 
 int loco_set_range_policy(loco_encoder* e, int policy) {
@@ -1199,14 +1272,10 @@ int loco_forward_checked(loco_encoder* e, const float* wav, const int32_t* mask,
     int rc = loco_forward(e, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    if (e->precision == 0) return LOCO_OK;  // the exact-fp32 mode stores no fp16 planes
     rc = loco_forward_status(e, nullptr, 0);
     if (rc != LOCO_E_RANGE || e->range_policy == 0) return rc;
     // out of the fp16 planes' range: the same batch again on the exact-fp32 MFMA kernels of this library
-    const int mode = e->precision;
-    e->precision = 0;
-    rc = loco_forward(e, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
-    e->precision = mode;
+    rc = forward_impl(e, 0, e->own, wav, mask, B, L, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     if (used_fp32) *used_fp32 = 1;
@@ -1217,7 +1286,7 @@ int loco_forward_checked(loco_encoder* e, const float* wav, const int32_t* mask,
 size_t loco_text_workspace_bytes(const loco_encoder* e, int32_t B, int32_t T) {
     Plan p;
     if (!e || !make_plan_tokens(e, B, T, p)) return 0;
-    return p.total;
+    return kStatusDevBytes + p.total;
 }
 
 int loco_text_max_positions(const loco_encoder* e) { return e ? e->text_pe_rows : 0; }
@@ -1234,14 +1303,18 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
     if (T > e->text_pe_rows)
         return fail(LOCO_E_INVALID, "loco_forward_text: %d tokens exceed the positional table (%d rows: max_text_positions)", T,
                     e->text_pe_rows);
-    if (workspace_bytes < p.total)
-        return fail(LOCO_E_WORKSPACE, "loco_forward_text: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    if (workspace_bytes < kStatusDevBytes + p.total)
+        return fail(LOCO_E_WORKSPACE, "loco_forward_text: workspace %zu < required %zu bytes", workspace_bytes, kStatusDevBytes + p.total);
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(LOCO_E_INVALID, "loco_forward_text: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    char* ws = reinterpret_cast<char*>(workspace);
+    Call c;
+    c.precision = e->precision;
+    c.st = e->own;
+    c.range_dev = reinterpret_cast<float*>(workspace);
+    char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* x0 = reinterpret_cast<float*>(ws + p.off_x0);
-    int rcb = range_begin(e, s);
+    int rcb = range_begin(e, c, s);
     if (rcb) return rcb;
     {
         Bracket br(e, s, K_FRAMES, 0.0, attention_mask ? 4.0 * B * (double)T : 0.0);
@@ -1256,10 +1329,10 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
                      reinterpret_cast<float*>(ws + p.off_ctx), reinterpret_cast<float*>(ws + p.off_qkv),
                      reinterpret_cast<float*>(ws + p.off_qp), reinterpret_cast<float*>(ws + p.off_ffn),
                      reinterpret_cast<_Float16*>(ws + p.off_xs0), reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
-    e->cur_splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
-    const int rc = e->precision >= 1 ? forward_f16x3(e, p, nullptr, out, hidden_states, bufs, s, true)
-                                     : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
-    return rc ? rc : range_end(e, s);
+    c.splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
+    const int rc = c.precision >= 1 ? forward_f16x3(e, c, p, nullptr, out, hidden_states, bufs, s, true)
+                                    : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
+    return rc ? rc : range_end(c, s);
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------
@@ -1425,6 +1498,8 @@ int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const
 }
 
 size_t loco_gemm_splitk_bytes(void) { return kSplitKBytes; }
+
+void loco_debug_reload_gemm_knobs(void) { reload_gemm_knobs(); }
 
 int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
                               const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc, int32_t M,

@@ -111,6 +111,7 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
                                   _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s);
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
+void reload_gemm_knobs();  // re-read the LOCO_GEMM_* A/B knobs from the environment (gemm_f16x3.hip)
 // hi/lo planes of x * scale (scale a power of two)
 hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s, float scale = 1.0f);
 // max |x| over n elements -> *out (one float, device); out must be zeroed by the caller
@@ -122,10 +123,11 @@ hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s);
 // represented to fp32 class relative to its own scale as long as its largest element sits well inside (2^-6, 65504) -- the
 // range include/loco_asr.h guarantees.
 //   * Tensors whose range follows from the weights alone are checked on the host, at no run-time cost: LayerNorm outputs
-//     (|y| <= sqrt(D) max|gamma| + max|beta|), conv0's GroupNorm + GELU output (the same with D = frames per clip), the
-//     attention context (a convex combination of V rows) -- loco_api.hip, static_range_check.
-//   * The unbounded ones -- GELU outputs of conv layers 1-5 and of the feed-forward intermediate, q|k|v, the feature
-//     projection -- are tracked where they are produced: the GEMM epilogue (and group_major_split) folds max|x| of what it
+//     (|y| <= sqrt(D) max|gamma| + max|beta|), the attention context (a convex combination of V rows) -- loco_api.hip,
+//     static_range_check.
+//   * The unbounded ones -- conv0's GroupNorm + GELU output (its bound grows with sqrt(frames per clip): useless for 10-minute
+//     clips), GELU outputs of conv layers 1-5 and of the feed-forward intermediate, q|k|v, the feature projection -- are tracked
+//     where they are produced: the GEMM epilogue (and group_major_split) folds max|x| of what it
 //     writes, taken on the fp32 value before conversion, into its stage's status word.  8 shards per stage (workgroup id mod
 //     8) so that no single address takes every workgroup's atomic; the word is read EARLY (range_peek, before the epilogue's
 //     arithmetic, so the load's latency is hidden) and a wave whose maximum is already covered skips the atomic -- the word
@@ -269,7 +271,7 @@ constexpr int kConv0Moments = 65;  // 10 first + 55 second moments
 size_t conv0_scratch_bytes(int B);
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
                                 float* out, void* scratch, float eps, hipStream_t s, void* out_hi = nullptr,
-                                void* out_lo = nullptr);
+                                void* out_lo = nullptr, float* range_slot = nullptr);
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
 size_t normalize_scratch_bytes(int B);
 hipError_t launch_normalize_waveform(const float* wav, const int32_t* mask, int B, long L, float pad, float* out, void* scratch,

@@ -151,6 +151,56 @@ class SpeechT5EncoderMI355X(_WeightHolder):
             _register(self, f"{b}feed_forward.output_dense.bias", (HIDDEN,))
 
 
+class _Slot:
+    """Everything ONE forward in flight owns: a stream, a workspace, a pinned status block (include/loco_asr.h,
+    loco_forward_async) and the ticket of the forward currently using them."""
+
+    def __init__(self, device, status_bytes):
+        self.stream = torch.cuda.Stream(device)
+        self.workspace = None
+        self.status = torch.zeros(status_bytes, dtype=torch.uint8).pin_memory()
+        self.ticket = None
+
+
+class ForwardTicket:
+    """A forward that has been enqueued and not yet checked.  ``result()`` waits for it (an event, not a device-wide
+    synchronisation), reads its numeric-range status and -- under range_policy "fp32" -- runs the batch once more on the
+    exact-fp32 kernels when the fp16 planes' range was left; then returns what ``forward`` would have returned."""
+
+    def __init__(self, enc, slot, x, m, out, frames, precision):
+        self._enc, self._slot = enc, slot
+        self._x, self._m = x, m  # kept alive until the forward has consumed them
+        self._out, self._frames = out, frames
+        self._precision = precision
+        self._done = torch.cuda.Event()
+        self._resolved = False
+        self.used_fp32 = False
+
+    def done(self) -> bool:
+        return self._done.query()
+
+    def result(self):
+        if not self._resolved:
+            enc, slot = self._enc, self._slot
+            self._done.synchronize()
+            if enc.range_policy != "off" and self._precision != "f32":
+                rc = enc._lib.loco_status_check(C.c_void_p(slot.status.data_ptr()), None, 0)
+                if rc == -5 and enc.range_policy == "fp32":
+                    with torch.cuda.device(self._out.device), torch.cuda.stream(slot.stream):
+                        enc._enqueue(slot, self._x, self._m, self._out, self._frames, "f32")
+                        slot.stream.synchronize()
+                    self.used_fp32 = True
+                elif rc < 0:
+                    _lib.check(rc, "loco_forward_async")
+            enc.last_range_fallback = self.used_fp32
+            enc.last_frames = self._frames
+            self._resolved = True
+            self._x = self._m = None
+            if slot.ticket is self:
+                slot.ticket = None
+        return BaseModelOutput(last_hidden_state=self._out, hidden_states=None, attentions=None)
+
+
 class _Ref:
     """weak-ish back reference that nn.Module does not register as a child."""
 
@@ -202,6 +252,9 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         # forward stays fully asynchronous; loco_forward_status can still be queried through range_report()).
         self.range_policy = "fp32"
         self.last_range_fallback = False
+        # forwards in flight (forward_async): slots of (stream, workspace, status block), used round-robin
+        self._slots = []
+        self._next_slot = 0
         self.eval()
 
     # -- lifetime ----------------------------------------------------------------------------------------
@@ -300,6 +353,89 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         _lib.check(self._lib.loco_forward_checked(self._handle, *args, stream, C.byref(used)), "loco_forward")
         self.last_range_fallback = bool(used.value)
 
+    # -- several forwards in flight ----------------------------------------------------------------------------
+    def set_inflight(self, k: int):
+        """Allow up to ``k`` forwards of this module in flight at once (forward_async).  The reference encodes one batch of two
+        utterances at a time (…base…py:67-68); such a batch is ~125 launches of 5-16 us and cannot fill the GPU, but nothing
+        orders batch k+1 behind batch k: each slot has its own stream, workspace and status block, the batches stay what they
+        are and so do their results (bit for bit)."""
+        if k < 1:
+            raise ValueError("inflight must be >= 1")
+        device = self._device()
+        self._ensure_handle(device)
+        self.drain()
+        n = int(self._lib.loco_status_bytes())
+        with torch.cuda.device(device):
+            self._slots = [_Slot(device, n) for _ in range(k)]
+        self._next_slot = 0
+
+    def drain(self):
+        """Resolve every forward still in flight (their tickets stay valid)."""
+        for slot in self._slots:
+            if slot.ticket is not None:
+                slot.ticket.result()
+
+    def _enqueue(self, slot, x, m, out, frames, precision):
+        B, L = x.shape
+        need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
+        if slot.workspace is None or slot.workspace.numel() < need:
+            slot.workspace = None
+            slot.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(self._lib.loco_forward_async(
+            self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
+            B, L, C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()),
+            slot.workspace.numel(), C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_async")
+
+    @torch.no_grad()
+    def forward_async(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, **kwargs) -> ForwardTicket:
+        """Enqueue one forward on the next slot and return its ticket without waiting; ``ticket.result()`` is the
+        BaseModelOutput.  Inputs are read after everything already queued on the CURRENT stream (the H2D copies that made
+        them); the slot's previous forward, if still unresolved, is resolved first."""
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        if input_values.dim() != 2:
+            raise ValueError(f"input_values must be [batch, samples], got {tuple(input_values.shape)}")
+        device = input_values.device
+        self._ensure_handle(device)
+        if self._device() != device:
+            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
+        if self._weights_dirty:
+            self.drain()  # re-finalising overwrites the weight planes in place: nothing may be reading them
+        if not self._slots:
+            self.set_inflight(2)
+        x = input_values
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.to(torch.float32).contiguous()
+        B, L = x.shape
+        T = int(self._lib.loco_output_frames(L))
+        if T < 1:
+            raise ValueError(f"input of {L} samples is shorter than one encoder frame (400 samples)")
+        m = None
+        if attention_mask is not None:
+            if attention_mask.shape != x.shape:
+                raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(x.shape)}")
+            m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+        slot = self._slots[self._next_slot]
+        self._next_slot = (self._next_slot + 1) % len(self._slots)
+        if slot.ticket is not None:
+            slot.ticket.result()
+        with torch.cuda.device(device):
+            self._sync_weights(device, T + 2)  # also grows the sinusoid table BEFORE anything is in flight on a longer clip
+            _lib.check(self._lib.loco_set_streams(self._handle, int(self.streams)), "set_streams")
+            cur = torch.cuda.current_stream(device)
+            slot.stream.wait_stream(cur)
+            with torch.cuda.stream(slot.stream):
+                out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+                frames = torch.empty((B,), dtype=torch.int32, device=device)
+                x.record_stream(slot.stream)
+                if m is not None:
+                    m.record_stream(slot.stream)
+                ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision)
+                self._enqueue(slot, x, m, out, frames, self.precision)
+                ticket._done.record(slot.stream)
+        slot.ticket = ticket
+        return ticket
+
     def workspace_bytes(self, batch: int, samples: int) -> int:
         self._ensure_handle(self._device())
         return int(self._lib.loco_workspace_bytes(self._handle, batch, samples))
@@ -376,11 +512,14 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         return BaseModelOutput(last_hidden_state=out, hidden_states=hidden, attentions=None)
 
 
-    def _launch(self, x, m, B, L, out, frames, device):
+    def _launch(self, x, m, B, L, out, frames, device, status):
+        # loco_forward_async: the captured forward writes ITS OWN status block on every replay (the handle's block would
+        # describe whatever eager forward ran last)
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        _lib.check(self._lib.loco_forward(self._handle, C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
-                                          B, L, C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None,
-                                          C.c_void_p(self._workspace.data_ptr()), self._workspace.numel(), stream), "loco_forward")
+        _lib.check(self._lib.loco_forward_async(self._handle, self.PRECISIONS[self.precision], C.c_void_p(x.data_ptr()),
+                                                C.c_void_p(m.data_ptr()) if m is not None else None, B, L, C.c_void_p(out.data_ptr()),
+                                                C.c_void_p(frames.data_ptr()), None, C.c_void_p(self._workspace.data_ptr()),
+                                                self._workspace.numel(), stream, C.c_void_p(status.data_ptr())), "loco_forward_async")
 
     def _forward_graph(self, x, m, B, L, T, device):
         """Capture loco_forward for this shape into a hipGraph once, then replay it: the C ABI enqueues on the caller's
@@ -403,13 +542,14 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
                 xs.copy_(x)
                 if ms is not None:
                     ms.copy_(m)
-                self._launch(xs, ms, B, L, outs, frs, device)  # eager warm-up (grows the sinusoid table if needed)
+                status = torch.zeros(int(self._lib.loco_status_bytes()), dtype=torch.uint8).pin_memory()
+                self._launch(xs, ms, B, L, outs, frs, device, status)  # eager warm-up (grows the sinusoid table if needed)
                 torch.cuda.synchronize(device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._launch(xs, ms, B, L, outs, frs, device)
-                self._graphs[key] = (g, xs, ms, outs, frs, self._workspace)
-            g, xs, ms, outs, frs, _ = self._graphs[key]
+                    self._launch(xs, ms, B, L, outs, frs, device, status)
+                self._graphs[key] = (g, xs, ms, outs, frs, self._workspace, status)
+            g, xs, ms, outs, frs, _, status = self._graphs[key]
             xs.copy_(x)
             if ms is not None:
                 ms.copy_(m)
@@ -417,9 +557,10 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             self.last_range_fallback = False
             if self.range_policy != "off":  # the captured forward carries its status copy: read it once the replay is done
                 torch.cuda.current_stream(device).synchronize()
-                if self._lib.loco_forward_status(self._handle, None, 0) != 0:
-                    if self.range_policy == "raise":
-                        _lib.check(-5, "loco_forward (hipGraph replay)")
+                rc = self._lib.loco_status_check(C.c_void_p(status.data_ptr()), None, 0)
+                if rc != 0:
+                    if self.range_policy == "raise" or rc != -5:
+                        _lib.check(rc, "loco_forward (hipGraph replay)")
                     out, frames = torch.empty_like(outs), torch.empty_like(frs)
                     self._forward_call((C.c_void_p(xs.data_ptr()), C.c_void_p(ms.data_ptr()) if ms is not None else None, B, L,
                                         C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None,

@@ -59,10 +59,11 @@ def read_slurp_split(data_path: str, split: str):
     return items
 
 
-def load_audio_16k(path: str):
+def load_audio_16k(path: str, device=None):
     """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56): files at another rate (Fisher:
     8 kHz, podcasts: 44.1 kHz) are converted ON THE DEVICE by loco_op_resample (resample.py) and come back as CUDA tensors,
-    which the feature extractor pads on the device; 16 kHz files stay numpy arrays on the host."""
+    which the feature extractor pads on the device; 16 kHz files stay numpy arrays on the host.  `device` = the rank's GPU: this
+    runs on loader threads, where torch.cuda.current_device() is 0 whatever the main thread selected."""
     try:
         import soundfile as sf
         x, sr = sf.read(path, dtype="float32", always_2d=True)
@@ -78,7 +79,7 @@ def load_audio_16k(path: str):
         if x.ndim == 2:
             x = x.mean(axis=1)
     if sr != 16000:
-        return importlib.import_module("loco-asr_amd.resample").resample_to_16k(x, int(sr))
+        return importlib.import_module("loco-asr_amd.resample").resample_to_16k(x, int(sr), device=device)
     return x
 
 
@@ -168,6 +169,9 @@ def main(argv=None):
     ap.add_argument("--random-init", action="store_true", help="deterministic synthetic weights (no checkpoint available)")
     ap.add_argument("--synthetic", type=int, default=0, help="encode N seeded synthetic clips instead of a corpus")
     ap.add_argument("--synthetic-seconds", type=float, default=5.0)
+    ap.add_argument("--synthetic-min-seconds", type=float, default=None,
+                    help="shortest synthetic clip (default: half of --synthetic-seconds); 2 with --synthetic-seconds 6 = a SLURP-like "
+                         "ragged corpus of 2-6 s utterances")
     ap.add_argument("--synthetic-exact", action="store_true",
                     help="every synthetic clip lasts exactly --synthetic-seconds (default: lengths drawn U[0.5, 1] x that, SURVEY.md 8d)")
     ap.add_argument("--classes-file", default=None,
@@ -183,6 +187,10 @@ def main(argv=None):
                     help="-m text: name or local directory of the SpeechT5 tokenizer (the reference's processor, …base…py:38)")
     ap.add_argument("--format", choices=["pickle", "npy"], default="pickle")
     ap.add_argument("--gather", action="store_true", help="all-gather embeddings so that rank 0 writes everything")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="batches in flight on the GPU at once (each on its own stream / workspace / status block).  The batches "
+                         "themselves are untouched -- the reference's pairs in corpus order -- and so are the results, bit for bit; "
+                         "a pair of 5 s clips alone cannot fill 256 CUs.  1 = one batch at a time, as the reference runs")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
@@ -199,15 +207,20 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     print("Running on", device)
-    if world > 1:
+    # LOCO_FORCE_COLLECTIVE=1 under a launcher: create the process group and issue every collective even at world size 1, so that
+    # a one-GPU box runs the real RCCL gather of --gather on device tensors (tests/test_gpu_rccl_world1.py)
+    collective = world > 1 or (os.environ.get("LOCO_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ)
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        dp.FORCE_COLLECTIVE = world == 1
 
     # ---- utterances
     if args.synthetic:
         n = int(args.synthetic_seconds * 16000)
-        lens = [n] * args.synthetic if args.synthetic_exact else la.synth.mixed_lengths(args.synthetic, n)
+        frac = 0.5 if args.synthetic_min_seconds is None else min(1.0, max(0.0, args.synthetic_min_seconds / args.synthetic_seconds))
+        lens = [n] * args.synthetic if args.synthetic_exact else la.synth.mixed_lengths(args.synthetic, n, min_fraction=frac)
         classes = load_classes(args.classes_file)
         order = sorted(classes)
         items = [(f"synthetic-{i:06d}", "", None, 16000, order[i % 101]) for i in range(args.synthetic)]
@@ -216,7 +229,7 @@ def main(argv=None):
     else:
         items = read_slurp_split(args.data_path, args.split)
         classes = load_classes(args.classes_file)
-        fetch = lambda i: load_audio_16k(items[i][2])
+        fetch = lambda i: load_audio_16k(items[i][2], device)
         lengths = [0] * len(items)  # unknown until decoded
     if args.window_seconds > 0:
         # windows become the units: (id_wk, text, path, sr, label) with a fetch that slices the parent recording
@@ -278,11 +291,40 @@ def main(argv=None):
             clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
         return idx, processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
 
+    def on_device(_device=device):  # loader threads start on GPU 0: select the rank's GPU for anything they do there
+        torch.cuda.set_device(_device)
+
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(args.loader_threads) if args.loader_threads > 0 else None
-    stager = ThreadPoolExecutor(1) if pool is not None else None
-    ahead = 2  # batches being prepared while one is on the GPU
+    pool = ThreadPoolExecutor(args.loader_threads, initializer=on_device) if args.loader_threads > 0 else None
+    stager = ThreadPoolExecutor(1, initializer=on_device) if pool is not None else None
+    ahead = max(2, args.inflight)  # batches being prepared while others are on the GPU
     pending = [stager.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if stager else []
+    encoder = model.speecht5.encoder
+    inflight = max(1, args.inflight)
+    if inflight > 1:
+        encoder.set_inflight(inflight)
+    gathers = 0
+
+    def finish(idx, emb):
+        """What follows a batch's forward: the optional gather, then the sink -- in batch order, whatever finished first."""
+        nonlocal gathers, frames_done
+        if args.gather and collective:
+            embs = dp.gather_ragged(emb, idx, len(items))  # the one large collective of the step
+            gathers += 1
+            if rank == 0:
+                for gid, e in enumerate(embs):
+                    if e is not None:
+                        sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
+        elif idx:
+            sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+        frames_done += int(emb.shape[0]) * int(emb.shape[1])
+
+    from collections import deque
+    import time
+    tickets = deque()
+    frames_done = 0
+    torch.cuda.synchronize(device)
+    t_loop = time.perf_counter()
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
         for rnd in range(n_rounds):
             if stager:
@@ -291,22 +333,38 @@ def main(argv=None):
                     pending.append(stager.submit(host_batch, rnd + ahead))
             else:
                 idx, feats = host_batch(rnd)
-            emb = torch.zeros((0, 1, 768), dtype=torch.float32, device=device)
-            if idx:
-                audios = feats.to(device)
-                emb = model.speecht5.encoder(**audios).last_hidden_state
-            if args.gather and world > 1:
-                embs = dp.gather_ragged(emb, idx, len(items))  # the one large collective of the step
-                if rank == 0:
-                    for gid, e in enumerate(embs):
-                        if e is not None:
-                            sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
-            elif idx:
-                sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+            if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
+                tickets.append((idx, None))
+            elif inflight > 1:
+                tickets.append((idx, encoder.forward_async(**feats.to(device))))
+            else:
+                tickets.append((idx, encoder(**feats.to(device))))
+            while len(tickets) >= inflight:  # the oldest batch: wait for it (an event), check its range status, hand it on
+                i0, t0 = tickets.popleft()
+                out = t0.result() if hasattr(t0, "result") else t0
+                finish(i0, out.last_hidden_state if out is not None else torch.zeros((0, 1, 768), dtype=torch.float32, device=device))
+        while tickets:
+            i0, t0 = tickets.popleft()
+            out = t0.result() if hasattr(t0, "result") else t0
+            finish(i0, out.last_hidden_state if out is not None else torch.zeros((0, 1, 768), dtype=torch.float32, device=device))
+    torch.cuda.synchronize(device)
+    t_loop = time.perf_counter() - t_loop  # decode / synthesis -> batching -> encoder -> sink, files closed
+    n_mine = sum(len(b) for b in my_batches)
+    print(f"Encoded {n_mine} utterances ({frames_done} frames, padded frames included) in {t_loop:.3f} s: "
+          f"{n_mine / max(t_loop, 1e-9):.1f} utterances/s, {frames_done / max(t_loop, 1e-9):,.0f} frames/s (--inflight {inflight})")
+    stats = {"utterances": n_mine, "frames": frames_done, "seconds": t_loop, "inflight": inflight}
+    if args.gather and collective:
+        import torch.distributed as dist
+        print(f"Embedding gathers issued: {gathers} (backend {dist.get_backend()}, world size {world})")
     for ex in (stager, pool):
         if ex is not None:
             ex.shutdown()
     print("Done!")
+    if collective:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return stats
 
 
 if __name__ == "__main__":

@@ -19,6 +19,7 @@ import torch.distributed as dist
 from torch import nn
 
 from . import _lib
+from . import dp as _dp
 
 METHODS = {"average": 0, "max": 1, "attention": 2, "self_attention": 2}
 D, NCLS = 768, 101
@@ -45,6 +46,7 @@ class IntentClassifierMI355X(nn.Module):
         self._dirty = True
         self._ws = None
         self._grads = None
+        self.allreduces_issued = 0  # gradient all-reduces of train_step (diagnostics: the DP path really ran)
 
     # ---- parameter plumbing -------------------------------------------------------------------------------
     def _flat(self) -> torch.Tensor:
@@ -87,6 +89,20 @@ class IntentClassifierMI355X(nn.Module):
         self.q.data.copy_(flat[:D].view(1, D))
         self.classifier[0].weight.data.copy_(flat[D:D + NCLS * D].view(NCLS, D))
         self.classifier[0].bias.data.copy_(flat[D + NCLS * D:])
+
+    @torch.no_grad()
+    def broadcast_parameters(self, src: int = 0, group=None):
+        """Data parallelism starts from ONE draw of the initial parameters: rank `src`'s flat vector to every rank (one
+        broadcast of 78 437 floats)."""
+        dev = self.q.device
+        if dev.type != "cuda":
+            raise RuntimeError("IntentClassifierMI355X runs only on an AMD GPU (no CPU path)")
+        flat = self._flat().to(dev)
+        dist.broadcast(flat, src=src, group=group)
+        self.q.data.copy_(flat[:D].view(1, D))
+        self.classifier[0].weight.data.copy_(flat[D:D + NCLS * D].view(NCLS, D))
+        self.classifier[0].bias.data.copy_(flat[D + NCLS * D:])
+        self._dirty = True
 
     def state_dict(self, *a, **k):
         if self._h is not None and not self._dirty:
@@ -156,13 +172,16 @@ class IntentClassifierMI355X(nn.Module):
         reported loss) are averaged over ranks with one all-reduce before Adam -- data-parallel SGD on the
         global batch."""
         loss, logits, grads = self.loss_and_grads(x, target)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and not _dp._skip_collective(dist.get_world_size(group)):
+            # one all-reduce of the flat gradient buffer (+ the loss); also issued in a process group of ONE rank when
+            # dp.FORCE_COLLECTIVE / LOCO_FORCE_COLLECTIVE=1 asks for it (the RCCL path on a one-GPU box): sum / 1 is exact
             w = dist.get_world_size(group)
             buf = torch.cat([grads, loss.reshape(1)])
             dist.all_reduce(buf, group=group)
             buf /= w
             grads.copy_(buf[:-1])
             loss = buf[-1]
+            self.allreduces_issued += 1
         hp = self.hyper
         dev = x.device
         with torch.cuda.device(dev):

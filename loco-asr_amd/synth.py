@@ -179,10 +179,10 @@ def batch(lengths, first_index: int = 0):
     return x, m
 
 
-def mixed_lengths(n_clips: int, max_samples: int, seed: int = 99):
-    """Lengths drawn U[0.5, 1]*max_samples (SURVEY.md §8d mixed-length variant)."""
+def mixed_lengths(n_clips: int, max_samples: int, seed: int = 99, min_fraction: float = 0.5):
+    """Lengths drawn U[min_fraction, 1]*max_samples (SURVEY.md §8d mixed-length variant: min_fraction 0.5)."""
     rng = np.random.Generator(np.random.Philox(seed))
-    return [int(max_samples * (0.5 + 0.5 * u)) for u in rng.random(n_clips)]
+    return [int(max_samples * (min_fraction + (1.0 - min_fraction) * u)) for u in rng.random(n_clips)]
 
 
 def conv_out_length(n: int) -> int:

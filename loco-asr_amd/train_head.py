@@ -38,15 +38,24 @@ def collate_fn(batch):
     return slurp_ids, pad_sequence(embeddings, batch_first=True), torch.stack(targets, dim=0)
 
 
-def evaluate(model, loader, device, n_items):
-    """sum-reduced soft-label CE and accuracy over a loader (train_classifier.py:136-152, 198-215)."""
-    loss, acc = 0.0, 0.0
+def evaluate(model, loader, device, n_items, collective=False):
+    """sum-reduced soft-label CE and accuracy over a loader (train_classifier.py:136-152, 198-215).  Under data parallelism
+    (`collective`) `loader` holds only this rank's batches and the two sums are added over the ranks with one all-reduce."""
+    sums = torch.zeros(2, dtype=torch.float64, device=device)
     for _, data, target in loader:
         pred = model(data.to(device)).squeeze(1)
         logp = torch.log_softmax(pred, dim=1)
-        loss += float(-(target.to(device).float() * logp).sum())
-        acc += float((pred.argmax(1) == target.to(device).argmax(1)).float().sum())
-    return loss / n_items, acc / n_items
+        sums[0] += -(target.to(device).float() * logp).sum().double()
+        sums[1] += (pred.argmax(1) == target.to(device).argmax(1)).double().sum()
+    if collective:
+        import torch.distributed as dist
+        dist.all_reduce(sums)
+    return float(sums[0]) / n_items, float(sums[1]) / n_items
+
+
+def strided_batches(n_items, batch_size, world, rank):
+    """Validation under data parallelism: the loader's batches in order (shuffle=False), batches rank, rank+W, ... to this rank."""
+    return [list(range(a, min(n_items, a + batch_size))) for a in range(0, n_items, batch_size)][rank::world]
 
 
 def epoch_batches(n_items, batch_size, world, rank, generator):
@@ -92,6 +101,9 @@ def main(argv=None):
     ap.add_argument("--folder", default=None, help="override extracted/<...> root")
     ap.add_argument("--epochs", type=int, default=100)
     ap.add_argument("--out-root", default=".")
+    ap.add_argument("--seed", type=int, default=None,
+                    help="seed of the head's initial parameters (the reference does not seed: train_classifier.py draws them from "
+                         "torch's default generator); under data parallelism rank 0's parameters are broadcast either way")
     args = ap.parse_args(argv)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -100,10 +112,15 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     print("Running on", device)
-    if world > 1:
+    # LOCO_FORCE_COLLECTIVE=1 (dp.py): create the process group and issue every collective even at world size 1, so that a
+    # one-GPU box exercises the RCCL gradient all-reduce of BASELINE.json configs[4] (tests/test_gpu_rccl_world1.py)
+    dp = importlib.import_module("loco-asr_amd.dp")
+    collective = world > 1 or (os.environ.get("LOCO_FORCE_COLLECTIVE") == "1" and "RANK" in os.environ)
+    if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        dp.FORCE_COLLECTIVE = world == 1
 
     folder = args.folder or ("extracted/speecht5" if args.version == "fine_tuned" else "extracted/speecht5_base")
     sets = [sink.EmbeddingsTargets(folder, args.modality, "train")]
@@ -124,9 +141,14 @@ def main(argv=None):
         ids, mine = epoch_batches(len(train_set), batch_size, world, rank, g)
         return ids, DataLoader(train_set, batch_sampler=mine, collate_fn=collate_fn)  # only this rank's batches are read from disk
 
-    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, collate_fn=collate_fn)
+    # every rank evaluates ITS share of the validation batches; the two sums meet in one all-reduce (evaluate)
+    val_loader = DataLoader(val_set, batch_sampler=strided_batches(len(val_set), batch_size, world, rank), collate_fn=collate_fn)
 
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
     model = la.IntentClassifierMI355X(method=args.pooling, lr=0.001, weight_decay=0.0001).to(device)
+    if collective:
+        model.broadcast_parameters()  # every rank starts from rank 0's draw
     save_folder = os.path.join(args.out_root, "checkpoints", args.version, args.modality, args.pooling)
     logs_folder = os.path.join(args.out_root, "results", args.version, args.modality, args.pooling, "logs")
     if rank == 0:
@@ -151,7 +173,7 @@ def main(argv=None):
                 text += f"Epoch [{epoch+1}/{args.epochs}], Iteration [{i+1}/{n_train_batches}], Loss: {float(loss):.4f}\n"
         epoch_loss /= max(1, n_batches)
         acc_train /= max(1, n_seen)
-        val_loss, acc_val = evaluate(model, val_loader, device, len(val_set))
+        val_loss, acc_val = evaluate(model, val_loader, device, len(val_set), collective)
         for k, v in (("loss", epoch_loss), ("val_loss", val_loss), ("acc", acc_train), ("val_acc", acc_val)):
             curves[k].append(v)
         line = (f"Epoch [{epoch+1}/{args.epochs}], Training Loss: {epoch_loss:.4f}, Training accuracy: {round(acc_train*100, 2)}, "
@@ -175,17 +197,20 @@ def main(argv=None):
             fh.write(text)
         write_curves(curves, os.path.join(os.path.dirname(logs_folder), "plots"))
     print("Training done!")
-    if world > 1:
+    if collective:
         import torch.distributed as dist
+        print(f"Gradient all-reduces issued: {model.allreduces_issued} (backend {dist.get_backend()}, world size {world})")
         dist.barrier()  # rank 0 has finished writing *_best.pth before any rank reads it
     model = la.IntentClassifierMI355X(method=args.pooling).to(device)
     model.load_state_dict(torch.load(os.path.join(save_folder, f"{tag}_best.pth")))
     print("Evaluating model on test set" + test_note)
     # the reference iterates the validation loader here and divides by len(test_set) (train_classifier.py:56, 211-212)
-    tl, ta = evaluate(model, val_loader, device, n_test)
+    tl, ta = evaluate(model, val_loader, device, n_test, collective)
     print(f"Test Loss: {tl:.4f}")
     print(f"Test Accuracy: {ta*100:.2f}")
     print("Evaluation done!")
+    if collective:
+        dist.destroy_process_group()
     return tl, ta
 
 

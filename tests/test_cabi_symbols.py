@@ -46,6 +46,29 @@ def test_host_only_entry_points():
     assert lib.loco_conv0_scratch_bytes(32) > 0
 
 
+def test_documented_precision_modes_are_the_accepted_ones():
+    """include/loco_asr.h documents the modes in LOCO_PRECISION_MODES; loco_set_precision accepts exactly the modes
+    loco_precision_name knows; the Python module offers the same set."""
+    text = open(os.path.join(ROOT, "include", "loco_asr.h")).read()
+    doc = re.search(r'#define LOCO_PRECISION_MODES "([^"]+)"', text).group(1)
+    documented = {int(a): b for a, b in (item.split() for item in doc.split(", "))}
+    lib = _libmod.load()
+    accepted = {m: lib.loco_precision_name(m).decode() for m in range(-2, 16) if lib.loco_precision_name(m)}
+    assert documented == accepted == {0: "f32", 1: "f16x3", 2: "f16x2"}
+    la = importlib.import_module("loco-asr_amd")
+    assert la.SpeechT5EncoderWithSpeechPrenetMI355X.PRECISIONS == {v: k for k, v in accepted.items()}
+    for mode, name in accepted.items():  # each documented mode has its paragraph in the header comment
+        assert re.search(rf'\*\s+{mode}\s+"{name}"', text), (mode, name)
+
+
+def test_status_block_is_a_plain_host_buffer():
+    lib = _libmod.load()
+    n = lib.loco_status_bytes()
+    assert 3000 < n < 16384 and n % 8 == 0
+    buf = ctypes.create_string_buffer(n)  # zeros: not a block filled by loco_forward_async
+    assert lib.loco_status_check(buf, None, 0) == -1 and b"status block" in lib.loco_last_error()
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_libmod, "_lib", None)
     monkeypatch.setattr(_libmod, "LIB_PATH", str(tmp_path / "nope.so"))

@@ -350,6 +350,7 @@ def test_gemm_f16x3_every_tile_form_agrees_bit_for_bit(K):
     try:
         for tile in (2, 1, 3, 4, 5, 6, 7, 8):
             os.environ["LOCO_GEMM_TILE"] = str(tile)
+            lib().loco_debug_reload_gemm_knobs()  # the A/B knobs are read once and again on request (gemm_f16x3.hip)
             for rep in range(3):
                 chi = torch.zeros(M, N, dtype=torch.float16, device="cuda")
                 clo = torch.zeros_like(chi)
@@ -366,6 +367,7 @@ def test_gemm_f16x3_every_tile_form_agrees_bit_for_bit(K):
                     assert nbad == 0, (tile, rep, nbad)
     finally:
         os.environ.pop("LOCO_GEMM_TILE", None)
+        lib().loco_debug_reload_gemm_knobs()
 
 
 def test_gemm_f16x3_batched_strided_conv_large():

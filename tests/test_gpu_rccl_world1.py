@@ -37,3 +37,79 @@ def test_bench_with_a_real_rccl_all_gather_at_world_size_one():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert "forced in a process group of one rank and checked" in d["config"]["collective"]
     assert d["config"]["workload"].startswith("SpeechT5-base speech encoder, synthetic 16 kHz 10 s clips, batch 8")
+
+
+def _launcher_env():
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _torchrun(script, args, env, force):
+    """`script` under the launcher with one rank (force) or as a plain process; only the child touches the GPU."""
+    if force:
+        env = dict(env, LOCO_FORCE_COLLECTIVE="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), script] + args
+    else:
+        cmd = [sys.executable, script] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_head_gradient_all_reduce_over_rccl_at_world_size_one(tmp_path):
+    """BASELINE.json configs[4] (train_classifier.py:104-115 on 8 GPUs): the head's data-parallel step all-reduces ONE flat
+    gradient buffer between loss_grad and Adam (intent_head.py train_step).  Here that all_reduce runs for real -- RCCL, device
+    buffer, process group of one rank -- inside train_head.py, and the parameters it leaves behind must equal, bit for bit, those
+    of the same run without a process group (sum over one rank, divided by one)."""
+    import numpy as np
+    import torch
+    import importlib
+    sink = importlib.import_module("loco-asr_amd.sink")
+    rng = np.random.default_rng(5)
+    for split, n in (("train", 48), ("devel", 20)):
+        folder = tmp_path / "emb" / split / "audio"
+        os.makedirs(folder)
+        for i in range(n):
+            T = int(rng.integers(20, 60))
+            tgt = np.zeros(101, dtype=np.int64)
+            tgt[int(rng.integers(0, 101))] = 1
+            sink.write_one(str(folder), f"u{i:04d}", rng.standard_normal((T, 768)).astype(np.float32), tgt)
+    script = os.path.join(ROOT, "loco-asr_amd", "train_head.py")
+    outs = {}
+    for force in (False, True):
+        root = tmp_path / ("dp" if force else "single")
+        os.makedirs(root)
+        # the head's initial parameters come from torch's default generator: seed it the same way in both runs
+        out = _torchrun(script, ["-m", "audio", "-p", "attention", "-v", "base", "--folder", str(tmp_path / "emb"), "--epochs", "2",
+                                 "--out-root", str(root), "--seed", "11"], _launcher_env(), force)
+        outs[force] = (out, torch.load(os.path.join(root, "checkpoints", "base", "audio", "attention", "speecht5_attention_audio_last.pth")))
+    assert "Gradient all-reduces issued: 6 (backend nccl, world size 1)" in outs[True][0], outs[True][0][-1500:]  # 3 batches x 2 epochs
+    assert "all-reduces issued" not in outs[False][0]
+    a, b = outs[False][1], outs[True][1]
+    assert set(a) == set(b) == {"q", "classifier.0.weight", "classifier.0.bias"}
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    # and training moved the parameters at all
+    assert float(a["classifier.0.bias"].abs().max()) > 0
+
+
+def test_extract_gather_over_rccl_at_world_size_one(tmp_path):
+    """BASELINE.json configs[3] ("RCCL all-gather of embeddings"): extract.py --gather routes every batch through
+    dp.gather_ragged -- two metadata gathers and the one large all_gather_into_tensor on DEVICE tensors over RCCL -- and rank 0
+    writes what comes out of the collective.  Its pickles must equal, byte for byte, those of the run that never touched a
+    process group."""
+    script = os.path.join(ROOT, "loco-asr_amd", "extract.py")
+    common = ["-m", "audio", "-s", "devel", "--synthetic", "7", "--synthetic-seconds", "1.5", "--random-init"]
+    out_a, out_b = str(tmp_path / "plain"), str(tmp_path / "gathered")
+    _torchrun(script, common + ["--out", out_a], _launcher_env(), False)
+    log = _torchrun(script, common + ["--out", out_b, "--gather"], _launcher_env(), True)
+    assert "Embedding gathers issued: 4 (backend nccl, world size 1)" in log, log[-1500:]  # pairs (0,1) (2,3) (4,5) (6)
+    fa, fb = os.path.join(out_a, "devel", "audio"), os.path.join(out_b, "devel", "audio")
+    names = sorted(os.listdir(fa))
+    assert len(names) == 7 and names == sorted(os.listdir(fb))
+    for n in names:
+        assert open(os.path.join(fa, n), "rb").read() == open(os.path.join(fb, n), "rb").read(), n

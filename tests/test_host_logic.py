@@ -3,6 +3,7 @@ and its reader, unit sharding."""
 import importlib
 import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
@@ -265,3 +266,56 @@ def test_feature_extractor_defers_normalisation_to_the_device():
     assert out.to("cpu")._pending_normalize == 0.0
     with pytest.raises(ValueError):
         fe(audio=clips, sampling_rate=16000, return_tensors="np")
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_present(monkeypatch):
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start `python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N ...` as a CHILD process (the shape of the driver's own command) and exit with the child's code --
+    before anything in the parent touches the GPU."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("the parent must not touch the GPU")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    # under a launcher whose world size disagrees, it is an error, not a second launch
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit, match="must agree"):
+        bench.main()
+
+
+def test_loader_threads_resample_on_the_ranks_own_gpu(monkeypatch, tmp_path):
+    """fetch() runs on ThreadPoolExecutor threads, where torch.cuda.current_device() is 0 whatever the main thread
+    selected -- every rank > 0 would resample on GPU 0.  The rank's device must be handed down explicitly."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.io import wavfile
+    extract = importlib.import_module("loco-asr_amd.extract")
+    resample = importlib.import_module("loco-asr_amd.resample")
+    path = str(tmp_path / "a.wav")
+    wavfile.write(path, 8000, (np.sin(np.arange(8000) * 0.01) * 2000).astype(np.int16))
+    seen = []
+
+    def fake(x, sr, device=None):
+        seen.append((int(sr), device, len(x)))
+        return torch.zeros(2 * len(x))
+
+    monkeypatch.setattr(resample, "resample_to_16k", fake)
+    rank_device = torch.device("cuda", 5)
+    with ThreadPoolExecutor(2) as pool:
+        y = list(pool.map(lambda _: extract.load_audio_16k(path, rank_device), range(3)))
+    assert len(y) == 3 and seen == [(8000, rank_device, 8000)] * 3

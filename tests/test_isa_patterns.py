@@ -30,6 +30,7 @@ def makefile_flags():
     """The flags the library is really built with (loco-asr_amd/csrc/Makefile), minus what -S does not take."""
     text = open(os.path.join(CSRC, "Makefile")).read()
     flags = re.search(r"^CXXFLAGS \?= (.*)$", text, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    flags += re.search(r"^override CXXFLAGS \+= (.*)$", text, re.M).group(1).split()  # what no environment can take away
     return [f for f in flags if f not in ("-fPIC",)]
 
 
@@ -56,6 +57,24 @@ def test_no_packed_fp32_op_cross_selects_its_low_lane(src, tmp_path):
 
 def test_the_build_disables_slp_packing():
     assert "-fno-slp-vectorize" in makefile_flags()
+    text = open(os.path.join(CSRC, "Makefile")).read()
+    assert re.search(r"^override CXXFLAGS \+= .*-fno-slp-vectorize", text, re.M), "a CXXFLAGS from the environment must not drop the flag"
+    assert "check_isa.py $@.tmp" in text, "`make` must inspect the linked library before installing it"
+
+
+def test_the_library_that_is_loaded_carries_no_banned_encoding():
+    """Not the flags, the product: disassemble the gfx950 code objects inside the libloco_asr.so the package loads."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(CSRC, "check_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lib = os.path.join(ROOT, "loco-asr_amd", "libloco_asr.so")
+    if not os.path.exists(os.path.join(mod.LLVM, "llvm-objdump")):
+        pytest.skip("llvm-objdump not available")
+    n, mfma, bad = mod.check(lib)
+    assert n >= 9 and mfma > 4000, (n, mfma)  # every kernel translation unit is in there, matrix instructions included
+    assert not bad, bad[:5]
+    assert mod.offenders_in_text("\tv_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]   // 000000001A2C: D3B04020\n")
 
 
 def test_the_detector_sees_the_form():

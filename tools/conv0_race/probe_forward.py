@@ -5,7 +5,8 @@ library with only the packed-tap conv0 kernel of commit 491647a^ swapped back in
 forward writes its 13 hidden states (a per-call argument), so a mismatch is located: which clip, and which is the FIRST
 hidden state that differs -- index 0 is the encoder's input, i.e. the prenet (conv stack, projection, positional conv).
 
-    LOCO_ASR_LIB=tools/conv0_race/libloco_oldconv0.so python tools/conv0_race/probe_forward.py [trials]
+    LOCO_ALLOW_BANNED_ISA=1 LOCO_ASR_LIB=tools/conv0_race/libloco_oldconv0.so python tools/conv0_race/probe_forward.py [trials]
+(_lib.load() refuses a foreign build that carries the banned encoding unless LOCO_ALLOW_BANNED_ISA=1 says this is the reproducer)
 """
 import ctypes as C
 import importlib

@@ -73,10 +73,14 @@ for rnd in range(6):
                 os.environ["LOCO_GEMM_TILE"] = tiles[v]
             if v in envvars:
                 os.environ[envvars[v]] = "1"
+            lib.loco_debug_reload_gemm_knobs()  # the knobs are read once, and again on request
             run(*s, lb=lb); e0.record(); run(*s, lb=lb); run(*s, lb=lb); e1.record(); torch.cuda.synchronize()
             if rnd: res[(v, s[0])].append(e0.elapsed_time(e1) / 2)
             if v in envvars:
                 os.environ.pop(envvars[v])
+            if v in tiles:
+                os.environ.pop("LOCO_GEMM_TILE", None)
+            lib.loco_debug_reload_gemm_knobs()
 for name, m, n, k, epi, osplit in shapes:
     nb = bufs[name][9]
     for v in libs:
