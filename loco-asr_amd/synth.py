@@ -124,6 +124,76 @@ def encoder_state_dict(seed: int = 0, layers: int = LAYERS) -> dict[str, np.ndar
     return sd
 
 
+def hashed_normal(key: str, shape, seed: int = 0) -> np.ndarray:
+    """float32 standard-normal array, a pure function of (key, seed, flat index): Box-Muller on two hashed uniforms."""
+    u1 = (hashed_uniform(key + "/u1", shape, seed).astype(np.float64) + 1.0) * 0.5
+    u2 = (hashed_uniform(key + "/u2", shape, seed).astype(np.float64) + 1.0) * 0.5
+    u1 = np.maximum(u1, 2.0 ** -25)
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+
+
+def encoder_state_dict_hf_init(seed: int = 0, layers: int = LAYERS) -> dict[str, np.ndarray]:
+    """A SECOND weight family for the goldens (g10): HuggingFace's own initialisation distributions
+    (SpeechT5PreTrainedModel._init_weights, modeling_speecht5.py: Linear / Embedding weights N(0, initializer_range = 0.02), conv
+    layers kaiming-normal, the positional conv N(0, 2 sqrt(1 / (128 * 768))) with weight-norm g = ||v||, the feature projection
+    U(+-1/sqrt(512))) drawn from the hash generator (independent of torch's RNG streams) -- plus what a TRAINED checkpoint has and
+    a fresh init has not: log-normal LayerNorm / GroupNorm gains (sigma 0.5), non-zero biases, and a few x100 OUTLIER CHANNELS in
+    every encoder LayerNorm gain and in the feed-forward bias (the massive-activation channels of real transformers).  The first
+    family (encoder_state_dict) is uniform and tuned for sharp attention; this one is normal, near-uniform in attention and
+    heavy-tailed in the residual stream."""
+    sd: dict[str, np.ndarray] = {}
+    N = lambda key, shape, std, mean=0.0: (hashed_normal(key, shape, seed + 1000) * np.float32(std) + np.float32(mean)).astype(np.float32)  # noqa: E731
+    U = lambda key, shape, a: (hashed_uniform(key, shape, seed + 1000) * np.float32(a)).astype(np.float32)  # noqa: E731
+
+    def gain(key, n, outliers=0):
+        g = np.exp(N(key, (n,), 0.5).astype(np.float64))
+        for j in range(outliers):  # deterministic outlier channels, x100
+            g[(_fnv1a(f"{key}/outlier{j}") + seed) % n] *= 100.0
+        return g.astype(np.float32)
+
+    p = "prenet."
+    sd[p + "masked_spec_embed"] = ((U(p + "masked_spec_embed", (HIDDEN,), 1.0) + 1) / 2).astype(np.float32)
+    for i, k in enumerate(CONV_KERNEL):
+        cin = 1 if i == 0 else CONV_DIM
+        name = f"{p}feature_encoder.conv_layers.{i}.conv.weight"
+        sd[name] = N(name, (CONV_DIM, cin, k), math.sqrt(2.0 / (cin * k)))  # kaiming_normal_, fan_in
+    n = p + "feature_encoder.conv_layers.0.layer_norm."
+    sd[n + "weight"] = gain(n + "weight", CONV_DIM)
+    sd[n + "bias"] = N(n + "bias", (CONV_DIM,), 0.1)
+    n = p + "feature_projection.layer_norm."
+    sd[n + "weight"] = gain(n + "weight", CONV_DIM)
+    sd[n + "bias"] = N(n + "bias", (CONV_DIM,), 0.1)
+    n = p + "feature_projection.projection."
+    sd[n + "weight"] = U(n + "weight", (HIDDEN, CONV_DIM), 1 / math.sqrt(CONV_DIM))
+    sd[n + "bias"] = U(n + "bias", (HIDDEN,), 1 / math.sqrt(CONV_DIM))
+    n = p + "pos_conv_embed.conv."
+    cg = HIDDEN // POS_CONV_GROUPS
+    v = N(n + "parametrizations.weight.original1", (HIDDEN, cg, POS_CONV_K), 2 * math.sqrt(1.0 / (POS_CONV_K * HIDDEN)))
+    sd[n + "bias"] = N(n + "bias", (HIDDEN,), 0.01)
+    sd[n + "parametrizations.weight.original0"] = np.sqrt((v.astype(np.float64) ** 2).sum(axis=(0, 1), keepdims=True)).astype(np.float32)
+    sd[n + "parametrizations.weight.original1"] = v
+    e = "wrapped_encoder."
+    sd[e + "layer_norm.weight"] = gain(e + "layer_norm.weight", HIDDEN, outliers=2)
+    sd[e + "layer_norm.bias"] = N(e + "layer_norm.bias", (HIDDEN,), 0.1)
+    sd[e + "embed_positions.pe_k.weight"] = N(e + "embed_positions.pe_k.weight", (2 * REL_MAX, HEAD_DIM), 0.02)
+    for l in range(layers):
+        b = f"{e}layers.{l}."
+        for proj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[f"{b}attention.{proj}.weight"] = N(f"{b}attention.{proj}.weight", (HIDDEN, HIDDEN), 0.02)
+            sd[f"{b}attention.{proj}.bias"] = N(f"{b}attention.{proj}.bias", (HIDDEN,), 0.02)
+        for ln in ("layer_norm", "final_layer_norm"):
+            sd[f"{b}{ln}.weight"] = gain(f"{b}{ln}.weight", HIDDEN, outliers=2)
+            sd[f"{b}{ln}.bias"] = N(f"{b}{ln}.bias", (HIDDEN,), 0.1)
+        sd[f"{b}feed_forward.intermediate_dense.weight"] = N(f"{b}feed_forward.intermediate_dense.weight", (FFN, HIDDEN), 0.02)
+        fb = N(f"{b}feed_forward.intermediate_dense.bias", (FFN,), 0.02)
+        for j in range(3):
+            fb[(_fnv1a(f"{b}ffn_bias/outlier{j}") + seed) % FFN] = np.float32(2.0 + j)
+        sd[f"{b}feed_forward.intermediate_dense.bias"] = fb
+        sd[f"{b}feed_forward.output_dense.weight"] = N(f"{b}feed_forward.output_dense.weight", (HIDDEN, FFN), 0.02)
+        sd[f"{b}feed_forward.output_dense.bias"] = N(f"{b}feed_forward.output_dense.bias", (HIDDEN,), 0.02)
+    return sd
+
+
 TEXT_VOCAB = 81          # SpeechT5Config.vocab_size
 MAX_TEXT_POSITIONS = 450  # SpeechT5Config.max_text_positions
 

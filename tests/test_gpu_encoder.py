@@ -57,6 +57,40 @@ def test_g2_ragged_batch_every_stage_and_layer(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
+def test_g10_second_weight_family_hf_init_with_outlier_channels(precision):
+    """a golden whose weights follow HF's own initialisation distributions, with log-normal LayerNorm / GroupNorm
+    gains and x100 outlier channels in every encoder LayerNorm (hidden states reach |x| ~ 300 in single channels) -- every stage
+    and all 13 hidden states, both fp32-class modes, and the f16x3 range guard must not have re-run anything in fp32."""
+    g = golden("g10_hf_init_outliers.npz")
+    sd = la.synth.encoder_state_dict_hf_init(0)
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                         {k: torch.from_numpy(v) for k, v in enc_sd.items()}, precision=precision).cuda()
+    enc = m.speecht5.encoder
+    x, msk = la.synth.batch(g["lengths"], first_index=int(g["first_index"]))
+    rows = torch.from_numpy(g["rows"])
+    st = {}
+    out = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda(), output_hidden_states=True, stage_taps=st)
+    assert st["frames"].cpu().tolist() == [249, 162]
+    assert not enc.last_range_fallback, "the outlier-channel model must stay inside the f16x3 range"
+    for name in ("conv_stack", "feature_projection", "prenet"):
+        assert rel_l2(st[name][:, rows], g[name]) < TOL, name
+    # With x100 outlier channels fp32 itself is the limit: HF's own fp32 pass sits up to 5.9e-5 from HF run in float64 (fixture key
+    # hf_fp32_error).  The hidden states are therefore compared with the FLOAT64 rows, against a FIXED bar of 1e-4 (north_star:
+    # 1e-3), and must not be worse than twice HF's own fp32 figure at the last layer; the actual figures go into the message.
+    errs = [rel_l2(h[:, rows], g["hidden_states_fp64"][i]) for i, h in enumerate(out.hidden_states)]
+    msg = f"g10 ({precision}) rel L2 vs HF float64 per hidden state: {[f'{e:.1e}' for e in errs]}; HF fp32: {[f'{e:.1e}' for e in g['hf_fp32_error']]}"
+    print(msg)
+    assert max(errs) < 1e-4, msg
+    assert errs[-1] < 2 * float(g["hf_fp32_error"][-1]), msg
+    for i in range(6):
+        assert rel_l2(out.hidden_states[i][:, rows], g["hidden_states"][i]) < TOL, (i, msg)
+    if precision == "f16x3":
+        rep = dict(((n, l), a) for n, l, a in enc.range_report())
+        assert max(rep.values()) < 65504 and min(rep.values()) > 2 ** -6
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_g3_headline_shape_batch2(precision):
     g = golden("g3_30s_x2.npz")
     rows = torch.from_numpy(g["rows"])

@@ -142,3 +142,26 @@ def test_b4_ragged_short_clip_at_the_far_end(oracle):
     for layer in (0, 11):
         ref = oracle.encoder_layer_rows(out.hidden_states[layer][3].cpu(), rows, nv, sd, f"wrapped_encoder.layers.{layer}.", pe_k)
         assert rel_l2(out.hidden_states[layer + 1][3, rows], ref) < 1e-5
+
+
+def test_real_sized_groupnorm_gain_does_not_send_ten_minute_clips_to_fp32(oracle):
+    """conv0's GroupNorm + GELU output used to be guarded by the worst-case bound sqrt(frames per clip) * max|gamma| +
+    max|beta|; a 10-minute clip has 1.92 M conv0 frames (sqrt = 1385), so ANY checkpoint with max|gamma| >= 47 would have run
+    every long batch twice (f16x3, sync, fp32).  The stage is measured now: with gamma x 50 (max|gamma| ~ 59) the largest element
+    is a few hundred, nothing is re-run, and the conv stack still reproduces the fp64 window oracle."""
+    sd = dict(la.synth.encoder_state_dict(0, layers=1))
+    k = "prenet.feature_encoder.conv_layers.0.layer_norm.weight"
+    sd[k] = (sd[k] * np.float32(50.0)).astype(np.float32)
+    assert float(np.abs(sd[k]).max()) > 47
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({a: torch.from_numpy(v) for a, v in pre.items()},
+                                                         {a: torch.from_numpy(v) for a, v in enc_sd.items()}, layers=1).cuda()
+    enc = m.speecht5.encoder
+    x = torch.from_numpy(la.synth.clip(78, L10))[None]
+    st = {}
+    out = enc(input_values=x.cuda(), stage_taps=st).last_hidden_state
+    assert not enc.last_range_fallback and bool(torch.isfinite(out).all())
+    amax = max(a for n, _, a in enc.range_report() if "conv_layers.0" in n)
+    assert 50 < amax < 65504, amax
+    for lo, hi in ((0, 4), (20000, 20004)):
+        assert rel_l2(st["conv_stack"][0, lo:hi], oracle.feature_encoder_window(x[0], sd, lo, hi)) < 1e-5
