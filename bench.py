@@ -77,7 +77,22 @@ def host_cores() -> int:
     return n
 
 
-def make_roofline(by, precision, steps):
+def traffic_for(stat_name, workload_key):
+    """PMC L2-miss bytes per launch of this kernel bucket FOR THIS WORKLOAD, from the newest committed
+    profiles/*_<bucket>_traffic.json whose "workload" field names the same shape (tools/pmc_traffic.py writes it) -> (bytes,
+    file name); (None, None) when no pass was taken on this shape -- a figure measured at 30 s x 32 says nothing about 10 min x 4."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{stat_name}_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload", "30sx32") == workload_key and "hbm_bytes_per_launch" in d:
+            return d["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def make_roofline(by, precision, steps, workload_key="30sx32"):
     """Roofline object of the DOMINANT kernel = the profiling bucket with the largest summed launch time in the timed region
     (the projection GEMM at 30 s x 32, attention at 10 min x 4): algorithmic FLOPs of its launches / their summed
     HIP-event duration against the dense MFMA peak of the instruction it issues; HBM-bound buckets against 8 TB/s."""
@@ -89,20 +104,15 @@ def make_roofline(by, precision, steps):
     kernel, bound, peak, mfma_per_product = BUCKETS.get(stat_name, (stat_name, "hbm", PEAK_HBM_GBPS, 1))
     if precision == "f16x2" and stat_name in ("gemm_f16x3", "pos_conv_f16x3_gemm"):
         mfma_per_product = 2  # the W_lo term is dropped in that mode
-    traffic = None
-    try:  # PMC HBM bytes per launch of the same kernel, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        import glob
-        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{stat_name}_traffic.json")))
-        if tf:
-            traffic = json.load(open(tf[-1]))["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
+    # PMC bytes per launch of the same kernel on the same workload, from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py);
+    # counters cannot be read inside this process, so this is never a live figure: traffic_source names the file it came from
+    traffic, traffic_source = traffic_for(stat_name, workload_key)
     if bound == "mfma":
         ach, unit = g["flops"] / (g["ms"] * 1e-3) / 1e12, "TFLOP/s"
     else:
         ach, unit = g["bytes"] / (g["ms"] * 1e-3) / 1e9, "GB/s"
     r = {"kernel": kernel, "bucket": stat_name, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-         "frac": round(ach / peak, 4), "traffic": traffic, "launches_per_step": g["launches"] / steps,
+         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": g["launches"] / steps,
          "avg_launch_ms": round(g["ms"] / g["launches"], 4), "share_of_kernel_time": round(g["ms"] / sum(v["ms"] for v in cands.values()), 3),
          "flops_per_launch_avg": g["flops"] / g["launches"], "algorithmic_bytes_per_launch_avg": g["bytes"] / g["launches"]}
     if mfma_per_product > 1:
@@ -164,7 +174,9 @@ def main():
                     help="N = 1 only: create the RCCL process group of one rank anyway and issue the per-step all_gather_into_tensor on "
                          "the device embeddings (what every rank does at N > 1), then check the gathered tensor against the local one")
     ap.add_argument("--cpu-sample-clips", type=int, default=8,
-                    help="clips of the same workload the CPU oracle is timed on (1 warm-up + --cpu-reps timed passes, median)")
+                    help="clips of the same workload the CPU oracle is timed on (1 warm-up + --cpu-reps timed passes, median).  Default 8 "
+                         "(batch 8: ~20 s per pass on 16 cores, so the default run stays within minutes); 32 = the full configuration "
+                         "SURVEY.md 8d names (batch 32: ~80 s per pass, 17 GB of host memory) -- same frames/s within a few percent")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
 
@@ -261,7 +273,8 @@ def main():
                                "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 and s["flops"] else None,
                                "gbps": (s["bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 and s["bytes"] else None}
                    for s in stats}
-        roofline = make_roofline(by, args.precision, args.steps)
+        wkey = f"{args.clip_seconds:g}sx{B}" if args.clip_seconds < 60 else f"{args.clip_seconds / 60:g}minx{B}"
+        roofline = make_roofline(by, args.precision, args.steps, wkey)
         whole = flops_per_clip(T) * B * world * args.steps / elapsed / 1e12
         result = {
             "metric": "audio frames/sec SpeechT5-base encoder, 30s×bs32 @1/2/4/8 GPU; embed L2 vs HF",
@@ -269,9 +282,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f16x3": "f16x3 (fp16 hi+lo operands, 3 MFMAs per product, fp32 accumulate)", "f32": "f32",
-                      "f16x2": "f16x2 (weights rounded to fp16, activations hi+lo, 2 MFMAs per product; opt-in, ~4e-4)"}[args.precision],
+                      "f16x2": "f16x2 (weights rounded to fp16, activations hi+lo, 2 MFMAs per product; opt-in, ~9e-4: at the 1e-3 bar, no margin)"}[args.precision],
             "precision": args.precision, "range_policy": enc.range_policy, "data": "synthetic",
             "config": {"workload": workload_label(args.clip_seconds, B),
+                       "cpu_baseline_sample": "skipped" if (args.no_cpu_baseline or world > 1) else
+                                              f"{max(1, min(args.cpu_sample_clips, B))} of the {B} clips, as one batch",
                        "clip_seconds": args.clip_seconds, "batch_per_gpu": B, "global_batch": B * world, "frames_per_clip": T,
                        "parallelism": f"dp{world}",
                        "collective": "all_gather(embeddings)" if world > 1 else
@@ -280,7 +295,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
         }
         # the other precision modes, short runs (3 steps), for reference: the exact-fp32 mode ("alt_precision") and the opt-in
-        # two-term mode ("opt_in_precision": weights rounded to fp16, ~4e-4 instead of ~1e-6 -- never what `value` reports)
+        # two-term mode ("opt_in_precision": weights rounded to fp16, ~9e-4 instead of ~1e-6 -- never what `value` reports)
         if world == 1 and not args.no_alt:
             for key, alt in (("alt_precision", "f32" if args.precision != "f32" else "f16x3"),
                              ("opt_in_precision", "f16x2" if args.precision != "f16x2" else "f16x3")):
@@ -298,7 +313,7 @@ def main():
                 enc.set_profiling(False)
                 enc.precision = args.precision
                 result[key] = {"precision": alt, "value": round(B * T * 3 / ealt, 1), "unit": "frames/s",
-                               "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3),
+                               "ms_per_step": round(ealt / 3 * 1e3, 3), "steps": 3, "roofline": make_roofline(st_alt, alt, 3, wkey),
                                "kernel_ms_per_step": {k_: round(v_["ms"] / 3, 3) for k_, v_ in st_alt.items()}}
         # The timed region above runs with per-kernel HIP events, which keep loco_forward on ONE stream.  Without them the
         # library's default for big batches is two half-batches on two streams (bit-identical output, loco_set_streams):

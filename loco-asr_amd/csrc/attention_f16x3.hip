@@ -67,6 +67,31 @@ __device__ __forceinline__ void ax_split_pair(const f32x2 pv, unsigned& hi, unsi
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(pv.y), "v"(hi));
 }
 
+// Diagnostic build only (-DLOCO_ATTN_DEBUG, tools/attn_nan_probe.py): every lane records, per key tile, a bit mask of the
+// quantities that were not finite at the end of that tile's iteration and the values of the bookkeeping scalars.
+#ifdef LOCO_ATTN_DEBUG
+__device__ float* g_attn_dbg = nullptr;  // [workgroup][thread][tile < 8][8 floats]
+#define AX_DBG(tile_, code_, S0_, S1_)                                                                                   \
+    if (g_attn_dbg && (tile_) < 8) {                                                                                     \
+        float* d_ = g_attn_dbg + (((long)blockIdx.x * 256 + tid) * 8 + (tile_)) * 8;                                     \
+        unsigned mask_ = 0;                                                                                              \
+        float smax_ = -INFINITY, smin_ = INFINITY;                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                 \
+            if (!(fabsf(S0_[e]) <= 3e38f) && S0_[e] != -INFINITY) mask_ |= 1u;                                           \
+            if (!(fabsf(S1_[e]) <= 3e38f) && S1_[e] != -INFINITY) mask_ |= 1u;                                           \
+            smax_ = fmaxf(smax_, fmaxf(S0_[e], S1_[e])); smin_ = fminf(smin_, fminf(S0_[e], S1_[e]));                    \
+            if (!(fabsf(o0[e]) <= 3e38f) || !(fabsf(o1[e]) <= 3e38f)) mask_ |= 2u;                                       \
+        }                                                                                                                \
+        if (!(fabsf(l_run) <= 3e38f)) mask_ |= 4u;                                                                       \
+        if (!(fabsf(alpha) <= 3e38f)) mask_ |= 8u;                                                                       \
+        if (!(fabsf(dsh) <= 3e38f)) mask_ |= 16u;                                                                        \
+        d_[0] = __uint_as_float(mask_ | ((code_) << 16)); d_[1] = m_run; d_[2] = alpha; d_[3] = dsh; d_[4] = l_run;      \
+        d_[5] = smax_; d_[6] = smin_; d_[7] = o0[0];                                                                     \
+    }
+#else
+#define AX_DBG(tile_, code_, S0_, S1_) {}
+#endif
+
 template <bool OUT_SPLIT>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16* __restrict__ qhi, const _Float16* __restrict__ qlo,
                                                                  const _Float16* __restrict__ khi, const _Float16* __restrict__ klo,
@@ -243,10 +268,19 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             _Pragma("unroll") for (int e = 1; e < 16; ++e) mxv = fmaxf(mxv, S0_[e]);                                   \
             _Pragma("unroll") for (int e = 0; e < 16; ++e) mxv = fmaxf(mxv, S1_[e]);                                   \
         }                                                                                                              \
-        {   /* the other lane half holds the other 32 keys of this query: one permlane32 swap, no LDS permute */       \
-            const unsigned mu = __builtin_bit_cast(unsigned, mxv);                                                     \
-            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);                                    \
-            mxv = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1])) + cb;                      \
+        {   /* the other lane half holds the other 32 keys of this query: one permlane32 swap, no LDS permute.       \
+               INLINE ASM ON TWO DISTINCT REGISTERS, deliberately: written as __builtin_amdgcn_permlane32_swap(mu, mu) hipcc    \
+               (ROCm 7.2) folds fmaxf(result[0], result[1]) to result[0] -- it treats the two results of a swap of equal    \
+               inputs as equal -- and every row then took the maximum of the LOWER lane half's 32 keys only.  Softmax is  \
+               shift-invariant, so nothing showed until a key of the upper half beat that maximum by more than ~11 nats:  \
+               P = exp(s - m) then leaves fp16, its hi plane is inf, lo = -inf and the row's context is NaN (found by the  \
+               second golden weight family, whose outlier tokens do exactly that; tests/test_gpu_ops.py pins it).       \
+               v_permlane32_swap a, b exchanges a[32..63] with b[0..31]: afterwards a holds the lower half's value in    \
+               both halves and b the upper half's.  One wait state between the VALU write of the inputs and the swap     \
+               (the compiler pads its own instructions, not inline asm). */                                            \
+            float ma_ = mxv, mb_ = mxv;                                                                                \
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ma_), "+v"(mb_));                \
+            mxv = fmaxf(ma_, mb_) + cb;                                                                                \
         }                                                                                                              \
         const float m_new = fmaxf(m_run, mxv);                                                                         \
         alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);                                                      \
@@ -393,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         l_run = l_run * alpha + (ps2.x + ps2.y);                                                                       \
         AX_STAMP(2)                                                                                                    \
         if (tq + 1 < ntiles) { AX_FINISH_TILE(SN0, SN1, tq + 1, mxr) }                                                 \
+        AX_DBG(tq, 1u, SN0, SN1)                                                                                       \
         AX_STAMP(3)                                                                                                    \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                               \
         __syncthreads();                                                                                               \
@@ -471,6 +506,11 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
 
 }  // namespace loco
 
+#ifdef LOCO_ATTN_DEBUG
+extern "C" int loco_debug_set_attn_dbg(void* buf) {  // diagnostic build only
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(loco::g_attn_dbg), &buf, sizeof(buf));
+}
+#endif
 #ifdef LOCO_ATTN_STAMPS
 extern "C" int loco_debug_set_attn_stamps(void* buf) {  // diagnostic build only: 8 x u64 per workgroup of the next launches
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(loco::g_attn_stamps), &buf, sizeof(buf));

@@ -59,11 +59,17 @@ __global__ __launch_bounds__(256) void head_scores_kernel(const float* __restric
 }
 
 // partial pooling over frames [t0, t1) of clip b.  method 0: sum, 1: max, 2: softmax-weighted sum with local max.
-// w2 (optional, attention backward): per-frame extra weight dalpha_t = dpooled_b . x_t is computed here and the
-// block accumulates sum_t alpha_t*dalpha_t*x_t and sum_t alpha_t*dalpha_t instead (alpha from the global lse).
+// BWD (attention backward): the query gradient of clip b is  dq_b = sum_t alpha_t dalpha_t (x_t - p_b),  dalpha_t = dpooled_b . x_t,
+// p_b = pooled_b = sum_t alpha_t x_t.  Written as  sum_t alpha_t dalpha_t x_t  -  (sum_t alpha_t dalpha_t) p_b  it is a one-pass
+// covariance: two sums of ~|dalpha| |p| that cancel to their difference -- on LayerNorm'd embeddings (a large common component p,
+// T = 1499 frames) fp32 keeps two digits of it (measured: 2.6e-2 relative to fp64, torch's fp32 autograd 1e-2).  Because
+// sum_t alpha_t (x_t - p_b) = 0, dalpha_t may be replaced by dalpha_t - dpooled_b . p_b = dpooled_b . (x_t - p_b):
+//     dq_b = sum_t alpha_t (dpooled_b . (x_t - p_b)) (x_t - p_b)                  = Cov_alpha(x) dpooled_b
+// -- every factor centred, nothing cancels, plain fp32 sums suffice.  The block accumulates that form (alpha from the global lse).
 template <int METHOD, bool BWD>
 __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restrict__ x, const float* __restrict__ z,
                                                            const float* __restrict__ lse, const float* __restrict__ dpooled,
+                                                           const float* __restrict__ pooled,
                                                            float* __restrict__ part_vec, Part* __restrict__ part, int T,
                                                            int splits) {
     __shared__ float w[kRows];
@@ -94,16 +100,20 @@ __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restri
             __syncthreads();
             l_loc = (red[0] + red[1]) + (red[2] + red[3]);
         } else {
-            // alpha_t * dalpha_t, dalpha_t = dpooled_b . x_t  (one wavefront per frame)
+            // alpha_t * dpooled_b . (x_t - p_b)  (one wavefront per frame; the centring happens element by element, before the dot)
             const float4* dp = reinterpret_cast<const float4*>(dpooled + (long)b * D);
+            const float4* pp = reinterpret_cast<const float4*>(pooled + (long)b * D);
+            float4 g4[3], p4[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { g4[i] = dp[lane + 64 * i]; p4[i] = pp[lane + 64 * i]; }
             float sacc = 0.f;
             for (int t = wave; t < nt; t += 4) {
                 const float4* xr = reinterpret_cast<const float4*>(xb + (long)t * D);
                 float acc = 0.f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const float4 a = xr[lane + 64 * i], g = dp[lane + 64 * i];
-                    acc += (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+                    const float4 a = xr[lane + 64 * i], g = g4[i], c = p4[i];
+                    acc += ((a.x - c.x) * g.x + (a.y - c.y) * g.y) + ((a.z - c.z) * g.z + (a.w - c.w) * g.w);
                 }
                 acc = wave_sum(acc);
                 const float wa = expf(z[(long)b * T + t0 + t] - lse[b]) * acc;
@@ -118,9 +128,14 @@ __global__ __launch_bounds__(256) void head_partial_kernel(const float* __restri
     }
     // weighted row sum / sum / max over the split: thread owns columns tid, tid+256, tid+512
     float a0 = METHOD == 1 ? -INFINITY : 0.f, a1 = a0, a2 = a0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;  // BWD: the clip's pooled vector, subtracted from every frame
+    if (METHOD == 2 && BWD) {
+        const float* pb = pooled + (long)b * D;
+        c0 = pb[tid]; c1 = pb[tid + 256]; c2 = pb[tid + 512];
+    }
     for (int t = 0; t < nt; ++t) {
         const float* xr = xb + (long)t * D;
-        const float v0 = xr[tid], v1 = xr[tid + 256], v2 = xr[tid + 512];
+        const float v0 = xr[tid] - c0, v1 = xr[tid + 256] - c1, v2 = xr[tid + 512] - c2;
         if (METHOD == 0) { a0 += v0; a1 += v1; a2 += v2; }
         if (METHOD == 1) { a0 = fmaxf(a0, v0); a1 = fmaxf(a1, v1); a2 = fmaxf(a2, v2); }
         if (METHOD == 2) { const float ww = w[t]; a0 = fmaf(ww, v0, a0); a1 = fmaf(ww, v1, a1); a2 = fmaf(ww, v2, a2); }
@@ -243,21 +258,17 @@ __global__ __launch_bounds__(256) void head_param_grads_kernel(const float* __re
     }
 }
 
-// dq = sum_b (G_b - S_b * pooled_b), G_b = sum_splits part_vec, S_b = sum_splits part.s   (attention pooling only)
-__global__ __launch_bounds__(256) void head_dq_kernel(const float* __restrict__ part_vec, const Part* __restrict__ part,
-                                                      const float* __restrict__ pooled, float* __restrict__ grads, int B,
-                                                      int splits) {
+// dq = sum_b sum_splits part_vec (the centred partial sums of head_partial_kernel<2, true>: nothing left to subtract)
+__global__ __launch_bounds__(256) void head_dq_kernel(const float* __restrict__ part_vec, float* __restrict__ grads, int B, int splits) {
     const int tid = threadIdx.x;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     for (int b = 0; b < B; ++b) {
-        float S = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         for (int s = 0; s < splits; ++s) {
             const float* pv = part_vec + ((long)b * splits + s) * D;
-            S += part[b * splits + s].s;
             g0 += pv[tid]; g1 += pv[tid + 256]; g2 += pv[tid + 512];
         }
-        const float* p = pooled + (long)b * D;
-        a0 += g0 - S * p[tid]; a1 += g1 - S * p[tid + 256]; a2 += g2 - S * p[tid + 512];
+        a0 += g0; a1 += g1; a2 += g2;
     }
     grads[tid] = a0; grads[tid + 256] = a1; grads[tid + 512] = a2;
 }
@@ -320,9 +331,9 @@ HeadWs carve(char* base, int B, int T) {
 template <bool BWD>
 void launch_partial(int method, const float* x, const HeadWs& w, int B, int T, hipStream_t s) {
     dim3 grid(w.splits, B);
-    if (method == 0) hipLaunchKernelGGL((head_partial_kernel<0, false>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.part_vec, w.part, T, w.splits);
-    else if (method == 1) hipLaunchKernelGGL((head_partial_kernel<1, false>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.part_vec, w.part, T, w.splits);
-    else hipLaunchKernelGGL((head_partial_kernel<2, BWD>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.part_vec, w.part, T, w.splits);
+    if (method == 0) hipLaunchKernelGGL((head_partial_kernel<0, false>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.pooled, w.part_vec, w.part, T, w.splits);
+    else if (method == 1) hipLaunchKernelGGL((head_partial_kernel<1, false>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.pooled, w.part_vec, w.part, T, w.splits);
+    else hipLaunchKernelGGL((head_partial_kernel<2, BWD>), grid, dim3(256), 0, s, x, w.z, w.lse, w.dpooled, w.pooled, w.part_vec, w.part, T, w.splits);
 }
 
 int head_forward_impl(loco_head* h, const float* x, int B, int T, const HeadWs& w, hipStream_t s) {
@@ -410,7 +421,7 @@ int loco_head_loss_grad(loco_head* h, const float* x, const float* target, int32
                        w.dpooled, loss, B);
     if (h->method == 2) {
         launch_partial<true>(2, x, w, B, T, s);
-        hipLaunchKernelGGL(head_dq_kernel, dim3(1), dim3(256), 0, s, w.part_vec, w.part, w.pooled, grads, B, w.splits);
+        hipLaunchKernelGGL(head_dq_kernel, dim3(1), dim3(256), 0, s, w.part_vec, grads, B, w.splits);
     } else if (hipMemsetAsync(grads, 0, D * 4, s) != hipSuccess) {
         return head_fail(LOCO_E_HIP, "memset failed");
     }

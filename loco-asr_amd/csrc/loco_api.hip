@@ -148,6 +148,8 @@ struct loco_encoder {
     // workspace of each forward; `own` is the status block of the forwards enqueued through loco_forward (pinned host memory)
     StatusBlock* own = nullptr;
     float* absmax_dev = nullptr;  // one float, weight preparation
+    bool debug_nonfinite = false;                 // LOCO_DEBUG_NONFINITE=1 at loco_create (dbg_check)
+    unsigned long long* debug_counter = nullptr;  // two words, device
     int range_policy = 1;         // loco_forward_checked: 1 = re-run out-of-range batches on the exact-fp32 kernels, 0 = report
     std::string range_static;     // non-empty: a weight-determined plane tensor (a LayerNorm output) leaves the range
     // profiling
@@ -319,9 +321,9 @@ int run_gemm(loco_encoder* e, hipStream_t s, const float* A, long lda, const flo
 }
 
 int run_ln(loco_encoder* e, hipStream_t s, const float* x, const float* g, const float* b, float* y, long rows, int dim,
-           _Float16* yhi = nullptr, _Float16* ylo = nullptr) {
+           _Float16* yhi = nullptr, _Float16* ylo = nullptr, float* nonfinite_slot = nullptr) {
     Bracket br(e, s, K_LN, 8.0 * rows * dim, (y && yhi ? 12.0 : 8.0) * rows * dim);
-    HIP_TRY(launch_layernorm(x, g, b, y, rows, dim, e->cfg.ln_eps, s, yhi, ylo));
+    HIP_TRY(launch_layernorm(x, g, b, y, rows, dim, e->cfg.ln_eps, s, yhi, ylo, nonfinite_slot));
     return LOCO_OK;
 }
 
@@ -407,6 +409,22 @@ int static_range_check(loco_encoder* e, const std::string& ln_prefix, int dim, h
 }
 
 bool nl_is_zero(const loco_encoder* e) { return e->cfg.layers == 0; }
+
+// Diagnostics, off unless the environment had LOCO_DEBUG_NONFINITE=1 when the handle was created: after each stage of the f16x3
+// forward, count the non-finite elements of what it wrote (host synchronisation per stage!) and name the FIRST stage that produced
+// any on stderr.  The range words cannot see NaNs (fmaxf drops them); this can.
+int dbg_check(loco_encoder* e, hipStream_t s, const char* stage, int layer, const void* p, size_t n, bool half, long row_len) {
+    if (!e->debug_nonfinite || !p) return LOCO_OK;
+    unsigned long long h[2] = {0, ~0ull};
+    HIP_TRY(hipMemcpyAsync(e->debug_counter, h, sizeof h, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_count_nonfinite(p, (long)n, half, e->debug_counter, s));
+    HIP_TRY(hipMemcpyAsync(h, e->debug_counter, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h[0])
+        fprintf(stderr, "[loco debug] non-finite values: %llu of %zu elements written by '%s' (layer %d); first at element %llu = row %llu, column %llu\n",
+                h[0], n, stage, layer, h[1], row_len ? h[1] / row_len : 0ull, row_len ? h[1] % row_len : 0ull);
+    return LOCO_OK;
+}
 
 int run_copy(loco_encoder* e, hipStream_t s, float* dst, const float* src, size_t n) {
     Bracket br(e, s, K_COPY, 0.0, 8.0 * n);
@@ -578,7 +596,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
     // share the words (a maximum does not care who contributes)
     int nslot = 0;
     auto slot = [&](const char* name, int layer = -1) -> float* {
-        if (!c.range_dev || !c.st || nslot >= kRangeMaxStages) return nullptr;
+        if (!c.range_dev || !c.st || nslot >= kFiniteStage) return nullptr;
         c.st->names[nslot] = name;
         c.st->layer[nslot] = layer;
         return c.range_dev + (size_t)kRangeShards * nslot++;
@@ -680,32 +698,58 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
                                  kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat, nullptr, nullptr,
                                  slot("attention q|k|v projections", l))))
             return rc;
+        if (e->debug_nonfinite) {
+            dbg_check(e, s, "x0 planes hi (layer input)", l, x0hi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "x0 planes lo (layer input)", l, x0lo, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "q planes hi", l, qshi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "q planes lo", l, qslo, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "k planes hi", l, scat.Khi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "k planes lo", l, scat.Klo, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "v^T planes hi", l, scat.Vthi, (size_t)B * kHidden * Tp, true, Tp);
+            dbg_check(e, s, "v^T planes lo", l, scat.Vtlo, (size_t)B * kHidden * Tp, true, Tp);
+        }
         // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320]
         if ((rc = run_gemm_split(e, c, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
                                  kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN,
                                  nullptr, nullptr, nullptr, nullptr, K_QP)))
             return rc;
+        dbg_check(e, s, "relative-position table Qp", l, qp, (size_t)M * kHeads * kRelN, false, kRelN);
         {
             const double tt = (double)T * T;
             Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
             HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
                                            Tp, s));
         }
+        if (e->debug_nonfinite) {
+            dbg_check(e, s, "attention context planes hi", l, chi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "attention context planes lo", l, clo, (size_t)M * kHidden, true, kHidden);
+        }
         if ((rc = run_gemm_split(e, c, s, chi, clo, kHidden, lw.so, kHidden, W(e, b + "attention.out_proj.bias"), nullptr, kHidden, tmp, nullptr,
                                  nullptr, kHidden, (int)M, kHidden, kHidden, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x0hi, x0lo)))
             return rc;
+        dbg_check(e, s, "out_proj + residual (fp32)", l, tmp, (size_t)M * kHidden, false, kHidden);
         if ((rc = run_ln(e, s, tmp, W(e, b + "layer_norm.weight"), W(e, b + "layer_norm.bias"), nullptr, M, kHidden, x1hi, x1lo))) return rc;
+        if (e->debug_nonfinite) {
+            dbg_check(e, s, "layer_norm planes hi", l, x1hi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "layer_norm planes lo", l, x1lo, (size_t)M * kHidden, true, kHidden);
+        }
         if ((rc = run_gemm_split(e, c, s, x1hi, x1lo, kHidden, lw.s1, kHidden, W(e, b + "feed_forward.intermediate_dense.bias"), nullptr, 0,
                                  nullptr, fhi, flo, e->cfg.ffn, (int)M, e->cfg.ffn, kHidden, kEpiGelu, 1, 0, 0, 1, 0, 0, nullptr, nullptr,
                                  nullptr, slot("feed_forward intermediate (GELU)", l))))
             return rc;
+        if (e->debug_nonfinite) {
+            dbg_check(e, s, "feed_forward intermediate planes hi", l, fhi, (size_t)M * e->cfg.ffn, true, e->cfg.ffn);
+            dbg_check(e, s, "feed_forward intermediate planes lo", l, flo, (size_t)M * e->cfg.ffn, true, e->cfg.ffn);
+        }
         if ((rc = run_gemm_split(e, c, s, fhi, flo, e->cfg.ffn, lw.s2, e->cfg.ffn, W(e, b + "feed_forward.output_dense.bias"), nullptr, kHidden,
                                  tmp, nullptr, nullptr, kHidden, (int)M, kHidden, e->cfg.ffn, kEpiResidual, 1, 0, 0, 1, 0, 0, nullptr, x1hi,
                                  x1lo)))
             return rc;
+        dbg_check(e, s, "feed_forward output + residual (fp32)", l, tmp, (size_t)M * kHidden, false, kHidden);
         const bool last = l == nl - 1;
         if ((rc = run_ln(e, s, tmp, W(e, b + "final_layer_norm.weight"), W(e, b + "final_layer_norm.bias"),
-                         last ? out : (hidden_states ? x0 : nullptr), M, kHidden, last ? nullptr : x0hi, last ? nullptr : x0lo)))
+                         last ? out : (hidden_states ? x0 : nullptr), M, kHidden, last ? nullptr : x0hi, last ? nullptr : x0lo,
+                         last && c.range_dev ? c.range_dev + (size_t)kRangeShards * kFiniteStage : nullptr)))
             return rc;
     }
     if (nl == 0 && (rc = run_copy(e, s, out, x0, (size_t)M * kHidden))) return rc;
@@ -726,8 +770,8 @@ int range_begin(loco_encoder* e, Call& c, hipStream_t s) {
     return LOCO_OK;
 }
 int range_end(const Call& c, hipStream_t s) {
-    if (c.precision >= 1 && c.st->used > 0)
-        HIP_TRY(hipMemcpyAsync(c.st->words, c.range_dev, sizeof(float) * kRangeShards * c.st->used, hipMemcpyDeviceToHost, s));
+    if (c.precision >= 1 && c.st->used > 0)  // all of them (3 KiB): the tracked stages and the reserved finite-check word
+        HIP_TRY(hipMemcpyAsync(c.st->words, c.range_dev, sizeof(float) * kRangeShards * kRangeMaxStages, hipMemcpyDeviceToHost, s));
     return LOCO_OK;
 }
 
@@ -786,6 +830,9 @@ loco_encoder* loco_create(const loco_config* cfg) {
     }
     memset(e->own, 0, sizeof(StatusBlock));
     e->own->magic = kStatusMagic;
+    if (const char* dbg = getenv("LOCO_DEBUG_NONFINITE")) {
+        e->debug_nonfinite = dbg[0] == '1' && hipMalloc(&e->debug_counter, 2 * sizeof(unsigned long long)) == hipSuccess;
+    }
     e->layers.resize(c.layers);
     build_expected(e);
     for (int i = 0; i < K_COUNT; ++i) {
@@ -817,6 +864,7 @@ void loco_destroy(loco_encoder* e) {
         free_split(l.s2);
     }
     (void)hipFree(e->absmax_dev);
+    (void)hipFree(e->debug_counter);
     if (e->own) (void)hipHostFree(e->own);
     (void)hipFree(e->sin_tab);
     (void)hipFree(e->text_embed);
@@ -1198,6 +1246,15 @@ int status_check(const StatusBlock* st, char* buf, size_t buflen) {
                  "activation range: max|x| = %.6g of '%s' is %s the range precision mode f16x3 represents to fp32 class "
                  "(%g <= max|x| < %g); use the exact-fp32 kernels for this input (loco_set_precision(enc, 0) / loco_forward_checked)",
                  (double)amax, where, over ? "above" : "below", (double)kRangeLo, (double)kRangeHi);
+        if (buf && buflen) snprintf(buf, buflen, "%s", msg);
+        return fail(LOCO_E_RANGE, "%s", msg);
+    }
+    // the finite check of the last LayerNorm: the range words above are maxima taken with fmaxf, which a NaN never enters -- an
+    // inf / NaN born inside a stage (not by leaving the range of a tracked plane tensor) is caught where everything ends up
+    if (st->used > 0 && stage_amax(st, kFiniteStage) > 0.f) {
+        const char* msg = "activation range: last_hidden_state holds non-finite values (inf / NaN) although every tracked plane tensor "
+                          "stayed inside the range precision mode f16x3 represents; use the exact-fp32 kernels for this input "
+                          "(loco_set_precision(enc, 0) / loco_forward_checked)";
         if (buf && buflen) snprintf(buf, buflen, "%s", msg);
         return fail(LOCO_E_RANGE, "%s", msg);
     }

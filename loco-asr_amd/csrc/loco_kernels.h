@@ -117,6 +117,9 @@ hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStrea
 // max |x| over n elements -> *out (one float, device); out must be zeroed by the caller
 hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s);
 
+// diagnostics: count the non-finite elements of a buffer (out[0] += count, out[1] = min(first index)); LOCO_DEBUG_NONFINITE=1
+hipError_t launch_count_nonfinite(const void* x, long n, bool half, unsigned long long* out, hipStream_t s);
+
 // ---- range tracking of tensors stored as fp16 hi/lo planes (precision mode f16x3) ------------------------------------------
 // hi = fp16(x) is inf from |x| >= 65520 on, and the pair (hi, lo) keeps 22 significant bits only while lo = fp16(x - hi) is a
 // normal fp16 number, i.e. for |x| >~ 2^-3; below that the ABSOLUTE error levels off at 2^-25.  A tensor is therefore
@@ -136,6 +139,7 @@ hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s);
 // The host reads the words after the forward (loco_forward_status) and decides (include/loco_asr.h).
 constexpr int kRangeShards = 8;
 constexpr int kRangeMaxStages = 96;
+constexpr int kFiniteStage = kRangeMaxStages - 1;  // reserved: set to +inf by the forward's last LayerNorm when a row is not finite
 __device__ __forceinline__ unsigned range_peek(const float* slot) {
     if (!slot) return 0xffffffffu;
     return __hip_atomic_load(reinterpret_cast<const unsigned*>(slot) + (blockIdx.x & (kRangeShards - 1)), __ATOMIC_RELAXED,
@@ -210,7 +214,9 @@ __device__ __forceinline__ float gelu_erf(float x) {
     q = fmaf(q, s, 4.592096508e-01f);
     q = fmaf(q, s, 1.151104808e+00f);
     const float h = 0.5f * __builtin_amdgcn_exp2f(-(q * s));  // erfc(|x| / sqrt 2) / 2
-    return x >= 0.f ? x * (1.0f - h) : fmaxf(x, -kSMax) * h;
+    // the clamp of the negative branch is a compare + select, not fmaxf: fmaxf(NaN, c) = c would launder a NaN input into a finite
+    // number (HF's GELU propagates it, and the forward's finite check must see it)
+    return x >= 0.f ? x * (1.0f - h) : (x < -kSMax ? -kSMax : x) * h;
 }
 
 // fp16 hi/lo split of two value pairs (a0,a1) and (b0,b1): hi = fp16(x) (hipcc emits one v_cvt_pk_f16_f32 per pair),
@@ -257,14 +263,14 @@ __device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
     const f32x2_t u = q * s;
     const f32x2_t h = {0.5f * __builtin_amdgcn_exp2f(-u.x), 0.5f * __builtin_amdgcn_exp2f(-u.y)};
     f32x2_t r;
-    r.x = x.x >= 0.f ? x.x * (1.0f - h.x) : fmaxf(x.x, -kSMax) * h.x;
-    r.y = x.y >= 0.f ? x.y * (1.0f - h.y) : fmaxf(x.y, -kSMax) * h.y;
+    r.x = x.x >= 0.f ? x.x * (1.0f - h.x) : (x.x < -kSMax ? -kSMax : x.x) * h.x;  // NaN-propagating clamp, see gelu_erf
+    r.y = x.y >= 0.f ? x.y * (1.0f - h.y) : (x.y < -kSMax ? -kSMax : x.y) * h.y;
     return r;
 }
 
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
-                            hipStream_t s, void* yhi = nullptr, void* ylo = nullptr);
+                            hipStream_t s, void* yhi = nullptr, void* ylo = nullptr, float* nonfinite_slot = nullptr);
 
 constexpr int kConv0Parts = 64;    // partial-moment blocks per clip
 constexpr int kConv0Moments = 65;  // 10 first + 55 second moments

@@ -20,7 +20,7 @@ template <int NV4, bool SPLIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                         const float* __restrict__ b, float* __restrict__ y,
                                                         _Float16* __restrict__ yhi, _Float16* __restrict__ ylo, long rows,
-                                                        float eps) {
+                                                        float eps, float* __restrict__ nonfinite_slot) {
     constexpr int D = NV4 * 256;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -41,6 +41,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+    // Finite check of the forward's LAST LayerNorm (loco_api.hip): an inf or NaN anywhere in the row makes its mean, hence its
+    // variance, NaN -- one wave-uniform compare per row, and an atomic only for a row that is bad (the word stays 0 otherwise).
+    // The range words cannot see NaNs (fmaxf drops them); whatever a stage upstream broke ends up in this row statistic.
+    if (nonfinite_slot && lane == 0 && !(rstd > 0.f)) atomicMax(reinterpret_cast<unsigned*>(nonfinite_slot) + (blockIdx.x & 7), 0x7f800000u);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) {
         const float4 gg = reinterpret_cast<const float4*>(g)[lane + 64 * i];
@@ -62,19 +66,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 hipError_t launch_layernorm(const float* x, const float* g, const float* b, float* y, long rows, int dim, float eps,
-                            hipStream_t s, void* yhi, void* ylo) {
+                            hipStream_t s, void* yhi, void* ylo, float* nonfinite_slot) {
     if (rows <= 0 || (!y && !yhi) || ((yhi == nullptr) != (ylo == nullptr))) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((rows + 3) / 4);
     _Float16* hi = (_Float16*)yhi;
     _Float16* lo = (_Float16*)ylo;
     if (dim == 768 && !hi)
-        hipLaunchKernelGGL((layernorm_kernel<3, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+        hipLaunchKernelGGL((layernorm_kernel<3, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps, nonfinite_slot);
     else if (dim == 768)
-        hipLaunchKernelGGL((layernorm_kernel<3, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+        hipLaunchKernelGGL((layernorm_kernel<3, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps, nonfinite_slot);
     else if (dim == 512 && !hi)
-        hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+        hipLaunchKernelGGL((layernorm_kernel<2, false>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps, nonfinite_slot);
     else if (dim == 512)
-        hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps);
+        hipLaunchKernelGGL((layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, x, g, b, y, hi, lo, rows, eps, nonfinite_slot);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -404,6 +408,31 @@ hipError_t launch_absmax(const float* x, long n, float* out, hipStream_t s) {
     if (n <= 0 || !x || !out) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, s, x, n, out);
+    return hipGetLastError();
+}
+
+// diagnostics (LOCO_DEBUG_NONFINITE=1): number of non-finite elements of an fp32 or fp16 buffer -> out[0] += count, out[1] = first index + 1
+template <typename T>
+__global__ void count_nonfinite_kernel(const T* __restrict__ x, long n, unsigned long long* __restrict__ out) {
+    unsigned long long cnt = 0, first = ~0ull;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = (float)x[i];
+        if (!(fabsf(v) <= 3.4e38f)) {
+            ++cnt;
+            if ((unsigned long long)i < first) first = (unsigned long long)i;
+        }
+    }
+    if (cnt) {
+        atomicAdd(out, cnt);
+        atomicMin(out + 1, first);
+    }
+}
+
+hipError_t launch_count_nonfinite(const void* x, long n, bool half, unsigned long long* out, hipStream_t s) {
+    if (n <= 0 || !x || !out) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (half) hipLaunchKernelGGL(count_nonfinite_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, n, out);
+    else hipLaunchKernelGGL(count_nonfinite_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, n, out);
     return hipGetLastError();
 }
 

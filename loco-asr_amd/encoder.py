@@ -218,8 +218,9 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
     # fp32 accumulate) -- ~1e-6 relative L2 of an fp64 evaluation end to end, 2.4x the speed of "f32";
     # "f32": every contraction on the exact fp32 MFMA (~1e-6).  Both are far inside the 1e-3 bar.
     # "f16x2" (opt-in, never the default): the weights of every projection / conv GEMM rounded to fp16 (after their
-    # per-tensor power-of-two scale), activations still hi + lo, attention products still three-term -- ~4e-4, inside the
-    # 1e-3 bar but no longer fp32 class; a third fewer matrix instructions in the GEMMs.
+    # per-tensor power-of-two scale), activations still hi + lo, attention products still three-term -- ~9e-4 on the goldens: AT the
+    # 1e-3 bar, not inside it with margin (no guarantee on other weights), and no longer fp32 class; a third fewer matrix
+    # instructions in the GEMMs.
     PRECISIONS = {"f32": 0, "f16x3": 1, "f16x2": 2}
 
     def __init__(self, layers: int = LAYERS, precision: str = "f16x3"):

@@ -48,3 +48,17 @@ def oracle():
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name))
+
+
+def record_figure(name, **values):
+    """Append measured parity figures (not only pass / fail) to gpurun_out/parity_figures.jsonl: the GPU box's copy comes back
+    with every gpurun call, and the round's summary is committed under profiles/."""
+    import json
+    import time
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_figures.jsonl"), "a") as fh:
+            fh.write(json.dumps({"test": name, "time": round(time.time(), 1), **values}) + "\n")
+    except OSError:
+        pass

@@ -116,12 +116,15 @@ def test_head_on_real_encoder_output():
     assert rel_l2(head(emb), ref(emb.cpu()).detach()) < 2e-5
 
 
-def test_configs4_head_training_step_on_real_encoder_output():
+@pytest.mark.parametrize("q_scale", [30.0, 1.0])
+def test_configs4_head_training_step_on_real_encoder_output(q_scale):
     """BASELINE.json configs[4] at the head's real operating point: [16, T, 768] embeddings produced by the full 12-layer
     encoder for 16 ragged 30 s clips, encoded in the reference's pairs (…base…py:67-68) so that every embedding carries the
     padded frames of its pair, zero-padded to the longest by the training collate_fn (train_classifier.py:47-51); then logits,
     loss, every gradient and three Adam steps of the HIP head against the torch oracle (itself pinned to the reference's
-    IntentClassifier by fixture g8), for the three pooling modes."""
+    IntentClassifier by fixture g8), for the three pooling modes.  q_scale 30: attention weights far from uniform (logits x.q of a
+    few units on |x_t| ~ 28); q_scale 1: the reference's own initial scale (q ~ 1e-3 N(0,1), intent_classifier.py:17), near-uniform
+    weights -- the regime every training run starts in."""
     from gpu_util import model
     from torch.nn.utils.rnn import pad_sequence
     m, _ = model()
@@ -142,7 +145,7 @@ def test_configs4_head_training_step_on_real_encoder_output():
         torch.manual_seed(11)
         ref = iho.IntentClassifierOracle(method)
         with torch.no_grad():
-            ref.q.mul_(30.0)  # |x_t| ~ 28 on LayerNorm'd embeddings: logits x.q of a few units -> attention weights far from uniform
+            ref.q.mul_(q_scale)
         head = la.IntentClassifierMI355X(method)
         head.load_state_dict(ref.state_dict())
         head = head.to("cuda")
@@ -158,18 +161,27 @@ def test_configs4_head_training_step_on_real_encoder_output():
             store.update(logits=pred.detach(), loss=float(loss), gw=model_.classifier[0].weight.grad, gb=model_.classifier[0].bias.grad,
                          gq=model_.q.grad.reshape(-1) if model_.q.grad is not None else None)
 
-        def bar(key, floor):
-            return max(floor, 3.0 * rel_l2(g32[key], g64[key]))
-
-        assert rel_l2(head(data), g64["logits"]) < bar("logits", 2e-5)
+        # FIXED bars against the fp64 truth (no bar that floats with the comparator).  torch's fp32 autograd is
+        # shown beside each figure for orientation only.  The query gradient is the delicate one: as a one-pass covariance
+        # (sum alpha dalpha x - (sum alpha dalpha) p) fp32 keeps two digits of it at T = 1499 (the first version of this head: 2.6e-2,
+        # torch fp32: ~1e-2); intent_head.hip accumulates the centred form Cov_alpha(x) dpooled instead, which has no cancellation,
+        # so 1e-5 is asked of it (measured 6e-7; torch's fp32 autograd: 6e-5 / 9e-6 in the two parametrisations).
+        fig = {}
+        fig["logits"] = (rel_l2(head(data), g64["logits"]), rel_l2(g32["logits"], g64["logits"]))
         gl, _, grads = head.loss_and_grads(data, target.cuda())
-        assert abs(float(gl) - g64["loss"]) < 2e-5 * max(1.0, abs(g64["loss"]))
-        assert rel_l2(grads[768:768 + 101 * 768].view(101, 768).cpu(), g64["gw"]) < bar("gw", 5e-5)
-        assert rel_l2(grads[768 + 101 * 768:].cpu(), g64["gb"]) < bar("gb", 5e-5)
+        fig["gw"] = (rel_l2(grads[768:768 + 101 * 768].view(101, 768).cpu(), g64["gw"]), rel_l2(g32["gw"], g64["gw"]))
+        fig["gb"] = (rel_l2(grads[768 + 101 * 768:].cpu(), g64["gb"]), rel_l2(g32["gb"], g64["gb"]))
         if method == "attention":
-            e_gpu, e_f32 = rel_l2(grads[:768].cpu(), g64["gq"]), rel_l2(g32["gq"], g64["gq"])
-            print(f"attention-pooling query gradient on [16, {data.shape[1]}, 768]: HIP head {e_gpu:.2e}, torch fp32 {e_f32:.2e} (vs fp64)")
-            assert e_gpu < max(1e-4, 3.0 * e_f32)
+            fig["gq"] = (rel_l2(grads[:768].cpu(), g64["gq"]), rel_l2(g32["gq"], g64["gq"]))
+        msg = f"{method}, q x {q_scale:g}, [16, {data.shape[1]}, 768] vs fp64 (HIP head, torch fp32): " + ", ".join(f"{k} ({a:.1e}, {b:.1e})" for k, (a, b) in fig.items())
+        print(msg)
+        from conftest import record_figure
+        record_figure("configs4_head_vs_fp64", method=method, q_scale=q_scale, figures={k: [float(a), float(b)] for k, (a, b) in fig.items()})
+        assert fig["logits"][0] < 2e-5, msg
+        assert abs(float(gl) - g64["loss"]) < 2e-5 * max(1.0, abs(g64["loss"])), msg
+        assert fig["gw"][0] < 5e-5 and fig["gb"][0] < 5e-5, msg
+        if method == "attention":
+            assert fig["gq"][0] < 1e-5, msg
         else:
             assert float(grads[:768].abs().max()) == 0.0
         # three optimisation steps against the fp32 oracle stepped the same way (train_classifier.py:104-116)

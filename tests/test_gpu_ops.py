@@ -304,6 +304,47 @@ def test_attention_core_f16x3(B, T, frames, oracle):
     assert rel_l2(ctx, ref) < 1e-5
 
 
+@pytest.mark.parametrize("key,gap", [(7, 30.0), (101, 30.0), (7, 80.0), (205, 14.0)])
+def test_attention_f16x3_row_max_covers_both_lane_halves(key, gap, oracle):
+    """Regression (round 3): each query's 64 keys of a tile sit in TWO lane halves (keys {0-3, 8-11, ...} / {4-7, 12-15, ...}); the
+    row maximum needs both.  Written with __builtin_amdgcn_permlane32_swap(m, m), hipcc folded max(result[0], result[1]) away and
+    every row used the LOWER half's maximum only.  Softmax is shift-invariant, so all goldens passed -- until the second weight
+    family (g10) produced "massive activation" keys: a key of the upper half that beats the lower half's maximum by more than
+    ~11 nats makes P = exp(s - m) > 65504, its fp16 hi plane inf, and the row's context NaN.  Here one key of the upper half
+    (bit 2 of its index set: 7 in the prologue's tile, 101 and 205 in the loop's tiles) outscores everything by `gap` nats for
+    every query; the output must be finite and match the fp64 oracle."""
+    assert key & 4
+    B, T = 2, 249
+    qkv = hu("atx.qkv", (B, T, 2304), 1.5)
+    qkv[..., :768] *= 0.125 * 1.5
+    u = hu("atx.u", (64,), 1.0)
+    u = u / u.norm()
+    qv, kv = qkv[..., :768].view(B, T, 12, 64), qkv[..., 768:1536].view(B, T, 12, 64)
+    qv -= (qv @ u)[..., None] * u           # remove, then plant: every query has component 1 along u ...
+    qv += u
+    kv -= (kv @ u)[..., None] * u           # ... and only the chosen key has one along it: its score leads by `gap`
+    base = (qv.transpose(1, 2) @ kv.transpose(1, 2).transpose(-1, -2)).abs().max()
+    kv[:, key] += (gap + float(base)) * u
+    pe_k = hu("atx.pe", (320, 64), 0.9)
+    q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
+    k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
+    v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
+    qp = (q @ pe_k.t()).contiguous()
+    Tp = (T + 63) // 64 * 64
+    qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
+    kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
+    vt = torch.zeros(B, 768, Tp)
+    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
+    vt[:, :, col[:T]] = qkv[..., 1536:].transpose(1, 2)
+    vh, vl = planes(vt.reshape(B * 768, Tp))
+    qpd = dev(qp)
+    ctx = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), None, ptr(ctx), B, T, Tp, stream()))
+    assert bool(torch.isfinite(ctx).all()), f"{int((~torch.isfinite(ctx)).any(-1).sum())} rows are not finite"
+    ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None, q_block=128).transpose(1, 2).reshape(B, T, 768)
+    assert rel_l2(ctx, ref) < 1e-5
+
+
 @pytest.mark.parametrize("epi,out_split", [(0, False), (1, True), (2, False)])
 def test_gemm_f16x3_large_tiles(epi, out_split):
     """Shapes that take the 256x256 / 16-wave LDS-DMA kernel (>= 768 tiles of 256x256) with a ragged last row tile."""

@@ -201,6 +201,26 @@ def test_weight_determined_ranges_are_checked_at_load_time(oracle):
         run(enc, sd, oracle, lengths=[16000])
 
 
+def test_non_finite_output_is_caught_even_when_every_tracked_stage_is_in_range():
+    """The range words are maxima taken with fmaxf, which a NaN never enters: an inf / NaN born INSIDE a stage (round 3: the
+    attention kernel's row maximum, see test_attention_f16x3_row_max_covers_both_lane_halves) sailed past them and came out as
+    NaN embeddings with status OK.  The forward's last LayerNorm now raises a flag for any row whose statistics are not finite.
+    Exercised with the one source of NaNs a test can plant without breaking a kernel: a NaN sample in the waveform (HF propagates
+    it too) -- 'raise' names the finite check, 'fp32' re-runs (and returns HF's NaNs), 'off' reports through the status call."""
+    enc, sd = build(lambda sd: None)
+    x, msk = la.synth.batch([16000, 12000])
+    x[1, 5000] = np.nan
+    xd, md = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
+    enc.range_policy = "raise"
+    with pytest.raises(_libmod.LocoError, match="non-finite values"):
+        enc(input_values=xd, attention_mask=md)
+    enc.range_policy = "fp32"
+    y = enc(input_values=xd, attention_mask=md).last_hidden_state
+    assert enc.last_range_fallback and bool(torch.isfinite(y[0]).all()) and not bool(torch.isfinite(y[1]).all())
+    y = enc(input_values=xd[:1], attention_mask=md[:1]).last_hidden_state  # the clean clip alone: nothing flagged
+    assert not enc.last_range_fallback and bool(torch.isfinite(y).all())
+
+
 def test_c_abi_checked_forward_reports_instead_of_rerunning_under_policy_0():
     def mod(sd):
         scale(sd, FFN1 + "weight", 40000.0)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Bisect the NaN of precision f16x3 on the g10 weight family: layer 1's stages one by one through the single-operator entry points,
+on the (finite) input hidden state the forward itself produced."""
+import ctypes as C, importlib, os, sys
+import numpy as np, torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import speecht5_oracle as oracle
+la = importlib.import_module("loco-asr_amd")
+L = importlib.import_module("loco-asr_amd._lib")
+lib = L.load()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sd = la.synth.encoder_state_dict_hf_init(0)
+pre, enc_sd = la.synth.split_state_dict(sd)
+x, msk = la.synth.batch([80000, 52000], first_index=40)
+m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                     {k: torch.from_numpy(v) for k, v in enc_sd.items()}, precision="f16x3").cuda()
+enc = m.speecht5.encoder
+enc.range_policy = "off"
+LAYER = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+for B_sel, name in ((slice(0, 2), "both clips"), (slice(0, 1), "clip 0 alone (no padding)")):
+    xs, ms = torch.from_numpy(x[B_sel]).cuda(), torch.from_numpy(msk[B_sel]).cuda()
+    out = enc(input_values=xs, attention_mask=ms, output_hidden_states=True)
+    torch.cuda.synchronize()
+    print(name, "-> finite per hidden state:", [bool(torch.isfinite(h).all()) for h in out.hidden_states])
+    bad = [(i, int((~torch.isfinite(h)).any(-1).sum())) for i, h in enumerate(out.hidden_states) if not torch.isfinite(h).all()]
+    if bad:
+        i, n = bad[0]
+        h = out.hidden_states[i]
+        rows = (~torch.isfinite(h)).any(-1).nonzero()
+        print(f"   first non-finite hidden state {i}: {n} rows; first rows (clip, frame): {rows[:12].tolist()} ... last {rows[-3:].tolist()}")
+out = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda(), output_hidden_states=True)
+hs = out.hidden_states[LAYER].clone()
+frames = enc.last_frames.clone()
+print("frames", frames.tolist(), "input finite", bool(torch.isfinite(hs).all()), "max", float(hs.abs().max()))
+lp = f"wrapped_encoder.layers.{LAYER}."
+w = lambda k: torch.from_numpy(sd[lp + k]).cuda()
+B, T, _ = hs.shape
+q = F.linear(hs, w("attention.q_proj.weight"), w("attention.q_proj.bias")) * 0.125
+k = F.linear(hs, w("attention.k_proj.weight"), w("attention.k_proj.bias"))
+v = F.linear(hs, w("attention.v_proj.weight"), w("attention.v_proj.bias"))
+pe = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"]).cuda()
+qp = (q.view(B, T, 12, 64).transpose(1, 2) @ pe.t()).contiguous()
+pl = lambda t: (t.half().contiguous(), (t - t.half().float()).half().contiguous())
+Tp = (T + 63) // 64 * 64
+qh, ql = pl(q.reshape(B * T, 768)); kh, kl = pl(k.reshape(B * T, 768))
+vt = torch.zeros(B, 768, Tp, device="cuda")
+col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
+vt[:, :, col[:T]] = v.transpose(1, 2)
+vh, vl = pl(vt.reshape(B * 768, Tp))
+ctx = torch.empty(B, T, 768, device="cuda")
+for fr, label in ((frames, "with the frame counts"), (None, "without mask")):
+    assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st()) == 0
+    torch.cuda.synchronize()
+    ref = oracle.attention_core(q.view(B, T, 12, 64).transpose(1, 2).double().cpu(), k.view(B, T, 12, 64).transpose(1, 2).double().cpu(),
+                                v.view(B, T, 12, 64).transpose(1, 2).double().cpu(), pe.double().cpu(), None if fr is None else fr.long().cpu(), q_block=128)
+    ref = ref.transpose(1, 2).reshape(B, T, 768)
+    fin = torch.isfinite(ctx)
+    print(f"attention op {label}: finite {bool(fin.all())}; non-finite rows per clip {[(int((~fin[b]).any(-1).sum())) for b in range(B)]}; "
+          f"rel L2 on finite rows {float((torch.nan_to_num(ctx).cpu().double() - ref).norm() / ref.norm()):.2e}")
+    if not fin.all():
+        bad = (~fin).view(B, T, 12, 64).any(-1).nonzero()
+        print("   bad (clip, frame, head):", bad[:24].tolist(), "... total", len(bad))
+        qd = q.view(B, T, 12, 64).transpose(1, 2).double().cpu(); kd = k.view(B, T, 12, 64).transpose(1, 2).double().cpu()
+        for (bb, tt, hh) in bad[:6].tolist():
+            sc = qd[bb, hh, tt] @ kd[bb, hh].t()
+            rel = (tt - torch.arange(T)).clamp(-160, 159) + 160
+            sc = sc + (qd[bb, hh, tt] @ pe.double().cpu().t())[rel]
+            nv = T if fr is None else int(fr[bb])
+            sc[nv:] = float("-inf")
+            tiles = [float(sc[j:j + 64].max()) for j in range(0, T, 64)]
+            print(f"   clip {bb} frame {tt} head {hh}: per-64-key-tile max of (score + bias) in nats: {[round(v, 2) for v in tiles]}; "
+                  f"min {float(sc[:nv].min()):.2f}; in log2 units x1.4427; ctx row sample {ctx[bb, tt, hh * 64: hh * 64 + 3].tolist()}")
+        good = fin.view(B, T, 12, 64).all(-1)
+        e = ((ctx.cpu().double() - ref).view(B, T, 12, 64)[good]).norm() / ref.view(B, T, 12, 64)[good].norm()
+        print(f"   rel L2 over the finite (row, head) pairs only: {float(e):.2e}")
