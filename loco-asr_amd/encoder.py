@@ -240,10 +240,6 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         self._workspace = None
         self._sin_rows = 0
         self._taps = None
-        # hipGraph replay for launch-bound shapes (a single 5 s utterance is ~110 kernel launches for ~1 ms of work):
-        # set use_graphs = True and every (batch, samples, mask, precision) shape is captured once and replayed.
-        self.use_graphs = False
-        self._graphs = {}
         # large batches run as two half-batches on two HIP streams (bit-identical, ~2 % faster: include/loco_asr.h,
         # loco_set_streams); set to 1 to keep everything on the caller's stream
         self.streams = 2
@@ -307,13 +303,10 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             rows = max(MAX_SPEECH_POSITIONS + PAD_TOKEN_ID + 1 + 2, min_sin_rows + 2)
             tab = sinusoid_table(rows).contiguous()
             shape = (C.c_int64 * 2)(rows, HIDDEN)
-            # captured hipGraphs hold the device pointer of the table this call replaces (the library frees the old one)
-            self._graphs.clear()
             _lib.check(self._lib.loco_set_weight(self._handle, b"prenet.pos_sinusoidal_embed.weights",
                                                  C.c_void_p(tab.data_ptr()), shape, 2), "sinusoid table")
             self._sin_rows = rows
         if self._weights_dirty:
-            self._graphs.clear()  # re-finalised weights live at new addresses
             _lib.check(self._lib.loco_finalize_weights(self._handle, stream), "finalize_weights")
             self._weights_dirty = False
 
@@ -469,12 +462,6 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             if attention_mask.shape != x.shape:
                 raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(x.shape)}")
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
-        if self.use_graphs and not output_hidden_states and stage_taps is None:
-            out, frames = self._forward_graph(x, m, B, L, T, device)
-            self.last_frames = frames
-            if return_dict is False:
-                return (out,)
-            return BaseModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
         with torch.cuda.device(device):
             self._sync_weights(device, T + 2)
             _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
@@ -511,64 +498,6 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         if return_dict is False:
             return tuple(v for v in (out, hidden) if v is not None)
         return BaseModelOutput(last_hidden_state=out, hidden_states=hidden, attentions=None)
-
-
-    def _launch(self, x, m, B, L, out, frames, device, status):
-        # loco_forward_async: the captured forward writes ITS OWN status block on every replay (the handle's block would
-        # describe whatever eager forward ran last)
-        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        _lib.check(self._lib.loco_forward_async(self._handle, self.PRECISIONS[self.precision], C.c_void_p(x.data_ptr()),
-                                                C.c_void_p(m.data_ptr()) if m is not None else None, B, L, C.c_void_p(out.data_ptr()),
-                                                C.c_void_p(frames.data_ptr()), None, C.c_void_p(self._workspace.data_ptr()),
-                                                self._workspace.numel(), stream, C.c_void_p(status.data_ptr())), "loco_forward_async")
-
-    def _forward_graph(self, x, m, B, L, T, device):
-        """Capture loco_forward for this shape into a hipGraph once, then replay it: the C ABI enqueues on the caller's
-        stream (plus, for large batches, a second stream forked from and joined back to it with events), allocates nothing
-        and never synchronises, which is exactly what stream capture requires."""
-        key = (B, L, m is not None, self.precision, int(self.streams), device.index)
-        with torch.cuda.device(device):
-            self._sync_weights(device, T + 2)
-            if self._weights_dirty is False and key not in self._graphs:
-                _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
-                _lib.check(self._lib.loco_set_streams(self._handle, int(self.streams)), "set_streams")
-                need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
-                if self._workspace is None or self._workspace.numel() < need or self._workspace.device != device:
-                    self._workspace = torch.empty(need, dtype=torch.uint8, device=device)
-                    self._graphs.clear()  # captured graphs point into the old workspace
-                xs = torch.empty_like(x)
-                ms = torch.empty_like(m) if m is not None else None
-                outs = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
-                frs = torch.empty((B,), dtype=torch.int32, device=device)
-                xs.copy_(x)
-                if ms is not None:
-                    ms.copy_(m)
-                status = torch.zeros(int(self._lib.loco_status_bytes()), dtype=torch.uint8).pin_memory()
-                self._launch(xs, ms, B, L, outs, frs, device, status)  # eager warm-up (grows the sinusoid table if needed)
-                torch.cuda.synchronize(device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._launch(xs, ms, B, L, outs, frs, device, status)
-                self._graphs[key] = (g, xs, ms, outs, frs, self._workspace, status)
-            g, xs, ms, outs, frs, _, status = self._graphs[key]
-            xs.copy_(x)
-            if ms is not None:
-                ms.copy_(m)
-            g.replay()
-            self.last_range_fallback = False
-            if self.range_policy != "off":  # the captured forward carries its status copy: read it once the replay is done
-                torch.cuda.current_stream(device).synchronize()
-                rc = self._lib.loco_status_check(C.c_void_p(status.data_ptr()), None, 0)
-                if rc != 0:
-                    if self.range_policy == "raise" or rc != -5:
-                        _lib.check(rc, "loco_forward (hipGraph replay)")
-                    out, frames = torch.empty_like(outs), torch.empty_like(frs)
-                    self._forward_call((C.c_void_p(xs.data_ptr()), C.c_void_p(ms.data_ptr()) if ms is not None else None, B, L,
-                                        C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None,
-                                        C.c_void_p(self._workspace.data_ptr()), self._workspace.numel()),
-                                       C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
-                    return out, frames
-            return outs.clone(), frs.clone()
 
 
 class _SpeechT5Core(nn.Module):

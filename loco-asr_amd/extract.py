@@ -182,6 +182,7 @@ def main(argv=None):
     ap.add_argument("--loader-threads", type=int, default=8,
                     help="decode / synthesise the NEXT batches on this many host threads while the GPU encodes the current one "
                          "(the reference loads inside collate_fn with num_workers=0, …base…py:53-57,67); 0 = inline")
+    ap.add_argument("--sink-threads", type=int, default=4, help="threads that wait for the D2H copies and write the per-utterance files")
     ap.add_argument("--text-prenet-state-dict", default="extracted/speecht5/mapping/text_prenet_state_dict.pickle")
     ap.add_argument("--tokenizer", default="microsoft/speecht5_asr",
                     help="-m text: name or local directory of the SpeechT5 tokenizer (the reference's processor, …base…py:38)")
@@ -279,14 +280,12 @@ def main(argv=None):
         n_rounds = dp.rounds(len(items), args.batch_size, world)  # equal on all ranks: collectives line up
 
     def host_batch(rnd):
-        """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads."""
+        """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads,
+        several BATCHES at a time (a batch of the reference is two clips: parallelism inside one would be two threads wide)."""
         idx = my_batches[rnd] if rnd < len(my_batches) else []
         if not idx:
             return idx, None
-        if pool is not None and args.window_seconds <= 0:  # the window cache of one decoded recording is not thread-safe
-            clips = list(pool.map(fetch, idx))
-        else:
-            clips = [fetch(i) for i in idx]
+        clips = [fetch(i) for i in idx]
         if any(torch.is_tensor(c) for c in clips):  # some files were resampled on the device: the whole batch is padded there
             clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
         return idx, processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
@@ -295,12 +294,13 @@ def main(argv=None):
         torch.cuda.set_device(_device)
 
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(args.loader_threads, initializer=on_device) if args.loader_threads > 0 else None
-    stager = ThreadPoolExecutor(1, initializer=on_device) if pool is not None else None
-    ahead = max(2, args.inflight)  # batches being prepared while others are on the GPU
-    pending = [stager.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if stager else []
-    encoder = model.speecht5.encoder
     inflight = max(1, args.inflight)
+    # the window cache of one decoded recording is not thread-safe: windows are prepared by ONE thread, in order
+    n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
+    pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None
+    ahead = max(2, 2 * inflight, n_loaders)  # batches being prepared while others are on the GPU
+    pending = [pool.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if pool else []
+    encoder = model.speecht5.encoder
     if inflight > 1:
         encoder.set_inflight(inflight)
     gathers = 0
@@ -325,12 +325,13 @@ def main(argv=None):
     frames_done = 0
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter()
-    with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
+    with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format, workers=args.sink_threads,
+                                                 max_pending=max(4, 4 * inflight)) as sink:
         for rnd in range(n_rounds):
-            if stager:
+            if pool:
                 idx, feats = pending.pop(0).result()
                 if rnd + ahead < n_rounds:
-                    pending.append(stager.submit(host_batch, rnd + ahead))
+                    pending.append(pool.submit(host_batch, rnd + ahead))
             else:
                 idx, feats = host_batch(rnd)
             if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
@@ -356,9 +357,8 @@ def main(argv=None):
     if args.gather and collective:
         import torch.distributed as dist
         print(f"Embedding gathers issued: {gathers} (backend {dist.get_backend()}, world size {world})")
-    for ex in (stager, pool):
-        if ex is not None:
-            ex.shutdown()
+    if pool is not None:
+        pool.shutdown()
     print("Done!")
     if collective:
         import torch.distributed as dist

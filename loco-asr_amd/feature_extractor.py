@@ -123,13 +123,14 @@ class SpeechT5FeatureExtractorMI355X:
                 raise ValueError("clips differ in length; use padding='longest'")
             lmax = len(clips[0])
         B = len(clips)
-        x = torch.full((B, lmax), float(self.padding_value), dtype=torch.float32)
-        m = torch.zeros((B, lmax), dtype=torch.int32)
+        pin = bool(self.pin_memory and torch.cuda.is_available())  # written straight into pinned memory (torch caches these blocks)
+        x = torch.empty((B, lmax), dtype=torch.float32, pin_memory=pin)
+        m = torch.empty((B, lmax), dtype=torch.int32, pin_memory=pin)
         for i, c in enumerate(clips):
             x[i, :len(c)] = torch.from_numpy(c)
+            x[i, len(c):] = float(self.padding_value)
             m[i, :len(c)] = 1
-        if self.pin_memory and torch.cuda.is_available():
-            x, m = x.pin_memory(), m.pin_memory()
+            m[i, len(c):] = 0
         out = BatchFeature(input_values=x)
         if self.return_attention_mask:
             out["attention_mask"] = m

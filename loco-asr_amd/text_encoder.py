@@ -78,8 +78,6 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         self._workspace = None
         self._sin_rows = 0
         self._taps = None
-        self.use_graphs = False
-        self._graphs = {}
         self.streams = 1
         self.last_frames = None
         self.eval()

@@ -5,11 +5,14 @@ Bar (BASELINE.json north_star): embeddings within 1e-3 relative L2 of the HF CPU
 are held to 2e-5 on full outputs and on every intermediate stage: "f32" (exact fp32 MFMA) lands at ~1e-6, the
 default "f16x3" (three fp16 MFMAs per fp32-class product) at ~3e-6.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden
+from conftest import ROOT, golden
 
 pytestmark = pytest.mark.gpu
 
@@ -216,70 +219,28 @@ def test_headline_batch_32x30s_properties():
     assert torch.equal(y, y2)
 
 
-def test_hipgraph_replay_matches_eager_and_is_faster_for_one_utterance():
-    """configs[0] shape (one 5 s utterance) is launch-bound: ~110 launches for ~1 ms of kernels.  The forward is
-    capturable as-is (no allocation / sync inside the C ABI); replay must be bitwise identical to eager."""
-    import time
+def test_the_c_abi_forward_is_stream_capturable_and_replays_bit_identically():
+    """The boundary allocates nothing and never synchronises inside loco_forward_async, so it can be captured into a hipGraph
+    (tools/graph_capture.py) and the replay is bit-identical -- also with new data of the same shape, and the captured forward
+    writes its own status block on every replay.  No timing claim: a replay takes what the eager forward takes (2.017 vs 2.016 ms
+    for one 5 s utterance, profiles/r03_hipgraph_trace.txt) -- the path is bound by its chain of small dependent kernels, not by
+    launches -- which is why the encoder module has no use_graphs switch."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from graph_capture import CapturedForward
     m, _ = model()
     enc = m.speecht5.encoder
     x, msk = la.synth.batch([80000])
     xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
     eager = enc(input_values=xs, attention_mask=ms).last_hidden_state
-    enc.use_graphs = True
-    try:
-        a = enc(input_values=xs, attention_mask=ms).last_hidden_state  # capture
-        b = enc(input_values=xs, attention_mask=ms).last_hidden_state  # replay
-        assert torch.equal(a, eager) and torch.equal(b, eager)
-        x2 = torch.from_numpy(la.synth.batch([80000], first_index=5)[0]).cuda()
-        c = enc(input_values=x2, attention_mask=ms).last_hidden_state  # same shape, new data -> same graph
-        enc.use_graphs = False
-        assert torch.equal(c, enc(input_values=x2, attention_mask=ms).last_hidden_state)
-
-        def timed(flag, n=30):
-            enc.use_graphs = flag
-            enc(input_values=xs, attention_mask=ms)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                enc(input_values=xs, attention_mask=ms)
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
-        te, tg = timed(False), timed(True)
-        print(f"5 s x 1 utterance: eager {te:.3f} ms, hipGraph replay {tg:.3f} ms")
-        # This shape is bound by the per-workgroup latency of tiny grids, not by launches: replay takes 0.8-1.0x of eager.  The
-        # bound is loose because hipGraph replay on this ROCm has a second mode -- in some processes every replay of the same
-        # graph takes ~5.3 ms instead of ~2.4-2.8 (seen with the round-1 library as well; the results are identical): the test
-        # is about bit-identity of the replay, the timing line is information.
-        assert tg < te * 2.5
-    finally:
-        enc.use_graphs = False
-
-
-def test_hipgraphs_are_dropped_when_the_sinusoid_table_or_the_weights_move():
-    """a captured graph holds the device pointer of the sinusoid table; a longer clip (> 4000 frames) makes the host
-    upload a bigger table and the library frees the old one, and re-loading weights re-finalises them at new addresses.  Both
-    must invalidate the captured graphs -- replaying the short clip's graph afterwards would read freed memory."""
-    m = la.SpeechT5ForSpeechToTextMI355X(2)
-    sd = la.synth.encoder_state_dict(0, 2)
-    pre, encsd = la.synth.split_state_dict(sd)
-    m.speecht5.encoder.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in encsd.items()})
-    m.speecht5.encoder.prenet.load_state_dict({k: torch.from_numpy(v) for k, v in pre.items()})
-    enc = m.to("cuda").speecht5.encoder
-    short = torch.from_numpy(la.synth.batch([16000])[0]).cuda()
-    long_ = torch.from_numpy(la.synth.batch([1_300_000], first_index=3)[0]).cuda()  # 4062 frames > the table's initial 4002 rows
-    eager_short = enc(input_values=short).last_hidden_state
-    enc.use_graphs = True
-    try:
-        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short) and len(enc._graphs) == 1
-        y_long = enc(input_values=long_).last_hidden_state  # grows the table: every captured graph is dropped first
-        assert tuple(y_long.shape) == (1, 4062, 768) and bool(torch.isfinite(y_long).all())
-        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short)  # re-captured against the new table
-        n_before = len(enc._graphs)
-        enc.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in encsd.items()})  # weights dirty -> re-finalise
-        assert torch.equal(enc(input_values=short).last_hidden_state, eager_short)
-        assert len(enc._graphs) <= n_before
-    finally:
-        enc.use_graphs = False
+    cap = CapturedForward(enc, xs, ms)
+    for _ in range(3):
+        out = cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, eager) and cap.status_code() == 0
+    x2 = torch.from_numpy(la.synth.batch([80000], first_index=5)[0]).cuda()
+    out = cap.replay(x2).clone()  # same shape, new data -> same graph
+    torch.cuda.synchronize()
+    assert torch.equal(out, enc(input_values=x2, attention_mask=ms).last_hidden_state)
 
 
 def test_two_stream_half_batches_are_bit_identical():
@@ -309,14 +270,17 @@ def test_two_stream_half_batches_are_bit_identical():
         enc.streams = 1
         assert torch.equal(nomask, enc(input_values=xs).last_hidden_state)
         enc.streams = 2
-        enc.use_graphs = True
-        a = enc(input_values=xs, attention_mask=ms).last_hidden_state  # capture
-        b = enc(input_values=xs, attention_mask=ms).last_hidden_state  # replay
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from graph_capture import CapturedForward
+        enc(input_values=xs, attention_mask=ms)  # loco_set_streams(2) is in effect for the capture
+        cap = CapturedForward(enc, xs, ms.to(torch.int32))  # the fork / join events of the two-stream schedule are capturable
+        a = cap.replay().clone()
+        b = cap.replay().clone()
+        torch.cuda.synchronize()
         assert torch.equal(a, one) and torch.equal(b, one)
         if frames_one is not None:
-            assert torch.equal(enc.last_frames, frames_one)
+            assert torch.equal(cap.frames, frames_one)
     finally:
-        enc.use_graphs = False
         enc.streams = 2
 
 

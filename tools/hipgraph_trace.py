@@ -31,17 +31,22 @@ def run():
     enc = m.to("cuda").speecht5.encoder
     x, msk = la.synth.batch([80000])
     xs, ms = torch.from_numpy(x).cuda(), torch.from_numpy(msk).cuda()
-    for flag in (False, True):  # warm-up, capture
-        enc.use_graphs = flag
-        for _ in range(3):
-            enc(input_values=xs, attention_mask=ms)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from graph_capture import CapturedForward
+    for _ in range(3):  # warm-up
+        enc(input_values=xs, attention_mask=ms)
+    cap = CapturedForward(enc, xs, ms)  # capture
+    for _ in range(3):
+        cap.replay(); torch.cuda.current_stream().synchronize()
     torch.cuda.synchronize()
     for flag in (False, True):
         time.sleep(0.6)
-        enc.use_graphs = flag
         t0 = time.perf_counter()
         for _ in range(N):
-            enc(input_values=xs, attention_mask=ms)
+            if flag:
+                cap.replay(xs, ms); torch.cuda.current_stream().synchronize(); assert cap.status_code() == 0
+            else:
+                enc(input_values=xs, attention_mask=ms)
         torch.cuda.synchronize()
         print(f"{'graph replay' if flag else 'eager'}: {(time.perf_counter() - t0) / N * 1e3:.3f} ms per forward (host clock, {N} forwards)", flush=True)
     time.sleep(0.6)
