@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_posconv_kernel(GemmSplitArg
 // per forward and possibly on several host threads -- and again only when a tool asks for it (loco_debug_reload_gemm_knobs).
 struct GemmKnobs {
     int tile = 0, narrow = 0;
-    bool nopersist = false, nocolgroup = false, no192 = false;
+    bool nopersist = false, nocolgroup = false, no192 = false, nosplitk = false;
 };
 static GemmKnobs read_gemm_knobs() {
     GemmKnobs k;
@@ -746,6 +746,7 @@ static GemmKnobs read_gemm_knobs() {
     k.nopersist = getenv("LOCO_GEMM_NOPERSIST") != nullptr;
     k.nocolgroup = getenv("LOCO_GEMM_NOCOLGROUP") != nullptr;
     k.no192 = getenv("LOCO_GEMM_NO192") != nullptr;
+    k.nosplitk = getenv("LOCO_GEMM_NOSPLITK") != nullptr;  // A/B: small problems as ONE launch each (no partial sums, no reduction kernel)
     return k;
 }
 static GemmKnobs& gemm_knobs() {
@@ -810,7 +811,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         // One or two short clips: 16 groups x B workgroups would each walk K = 6144 in 192 dependent k-tiles (200 us, the longest
         // kernel of a 2 ms forward).  Split-K over the taps: the slice becomes the inner half of z1 (GemmSplitArgs::z1_inner),
         // fp32 partial sums [clip][slice][group][frame][48], then splitk_reduce_posconv_kernel applies the epilogue.
-        if (a.splitk_ws && nb <= 64 && a.z1_inner == 1) {
+        if (a.splitk_ws && nb <= 64 && a.z1_inner == 1 && !gemm_knobs().nosplitk) {
             // a FIXED slice count: a clip's result must not depend on how many neighbours share its batch (the summation order
             // is part of the result), so within this regime every batch size takes the same eight slices of 24 k-tiles
             const int ks = 8;
@@ -853,7 +854,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     // slices computed as a batch dimension of the same kernel (fp32 partial sums in a workspace), then summed in a fixed
     // order -- bitwise reproducible -- by a reduction kernel that applies the epilogue.
     if (a.ktaps < 1 || a.ktaps > 3 || (!a.kchan && a.ktaps > 1 && a.K % (a.ktaps * 2 * SBK) != 0) || a.K / SBK >= 32768) return hipErrorInvalidValue;
-    if (a.splitk_ws && a.nb1 * a.nb2 == 1 && a.M <= kSplitKMaxM) {
+    if (a.splitk_ws && a.nb1 * a.nb2 == 1 && a.M <= kSplitKMaxM && !gemm_knobs().nosplitk) {
         const int bm = a.M >= 1024 ? 256 : 128;  // the tile the dispatch below picks for this M (N tile 128)
         const int tm = (a.M + bm - 1) / bm, tn = (a.N + 127) / 128;
         int ks = 256 / (tm * tn);

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import threading
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -174,12 +175,17 @@ class ForwardTicket:
         self._precision = precision
         self._done = torch.cuda.Event()
         self._resolved = False
+        self._lock = threading.Lock()  # result() may be called from the thread that enqueues (slot reuse) and from a consumer thread
         self.used_fp32 = False
 
     def done(self) -> bool:
         return self._done.query()
 
     def result(self):
+        with self._lock:
+            return self._result_locked()
+
+    def _result_locked(self):
         if not self._resolved:
             enc, slot = self._enc, self._slot
             self._done.synchronize()

@@ -319,35 +319,66 @@ def main(argv=None):
             sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
         frames_done += int(emb.shape[0]) * int(emb.shape[1])
 
-    from collections import deque
+    import queue
+    import threading
     import time
-    tickets = deque()
     frames_done = 0
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter()
+    empty = torch.zeros((0, 1, 768), dtype=torch.float32, device=device)
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format, workers=args.sink_threads,
                                                  max_pending=max(4, 4 * inflight)) as sink:
-        for rnd in range(n_rounds):
-            if pool:
-                idx, feats = pending.pop(0).result()
-                if rnd + ahead < n_rounds:
-                    pending.append(pool.submit(host_batch, rnd + ahead))
-            else:
-                idx, feats = host_batch(rnd)
-            if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
-                tickets.append((idx, None))
-            elif inflight > 1:
-                tickets.append((idx, encoder.forward_async(**feats.to(device))))
-            else:
-                tickets.append((idx, encoder(**feats.to(device))))
-            while len(tickets) >= inflight:  # the oldest batch: wait for it (an event), check its range status, hand it on
-                i0, t0 = tickets.popleft()
-                out = t0.result() if hasattr(t0, "result") else t0
-                finish(i0, out.last_hidden_state if out is not None else torch.zeros((0, 1, 768), dtype=torch.float32, device=device))
-        while tickets:
-            i0, t0 = tickets.popleft()
-            out = t0.result() if hasattr(t0, "result") else t0
-            finish(i0, out.last_hidden_state if out is not None else torch.zeros((0, 1, 768), dtype=torch.float32, device=device))
+        # Two host threads share the loop when batches are in flight: this one stages (H2D) and enqueues forwards, the consumer
+        # waits for each batch IN ORDER (an event, not a device-wide synchronisation), checks its range status and hands it to the
+        # gather / the sink.  The queue is bounded: at most `inflight` batches wait behind the one being finished.
+        todo = queue.Queue(maxsize=inflight)
+        failure = []
+
+        def consume():
+            try:
+                torch.cuda.set_device(device)
+                with torch.no_grad():
+                    while True:
+                        item = todo.get()
+                        if item is None:
+                            return
+                        i0, t0 = item
+                        out = t0.result() if hasattr(t0, "result") else t0
+                        finish(i0, out.last_hidden_state if out is not None else empty)
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the producing thread
+                failure.append(e)
+                while todo.get() is not None:  # keep draining so that the producer never blocks on a dead consumer
+                    pass
+
+        consumer = threading.Thread(target=consume, name="loco-finish") if inflight > 1 else None
+        if consumer:
+            consumer.start()
+        try:
+            for rnd in range(n_rounds):
+                if failure:
+                    break
+                if pool:
+                    idx, feats = pending.pop(0).result()
+                    if rnd + ahead < n_rounds:
+                        pending.append(pool.submit(host_batch, rnd + ahead))
+                else:
+                    idx, feats = host_batch(rnd)
+                if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
+                    item = (idx, None)
+                elif inflight > 1:
+                    item = (idx, encoder.forward_async(**feats.to(device)))
+                else:
+                    item = (idx, encoder(**feats.to(device)))
+                if consumer:
+                    todo.put(item)
+                else:
+                    finish(item[0], item[1].last_hidden_state if item[1] is not None else empty)
+        finally:
+            if consumer:
+                todo.put(None)
+                consumer.join()
+        if failure:
+            raise failure[0]
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter() - t_loop  # decode / synthesis -> batching -> encoder -> sink, files closed
     n_mine = sum(len(b) for b in my_batches)

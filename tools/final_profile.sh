@@ -18,6 +18,6 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_
   echo "pmc $n done"
 done
 python3 tools/pmc_traffic.py gemm_f16x3_dma_kernel $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv) $O/gemm_f16x3_traffic.json \
-  --exclude "<0, false, 2, 2, 2," --exclude "<4, false, 8, 1,"
-python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv) $O/attention_f16x3_traffic.json
+  --exclude "<0, false, 2, 2, 2," --exclude "<4, false, 8, 1," --workload 30sx32
+python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv) $O/attention_f16x3_traffic.json --workload 30sx32
 cp $(ls $O/stats/*/*kernel_stats.csv) $O/kernel_stats.csv
