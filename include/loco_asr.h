@@ -343,6 +343,12 @@ int32_t loco_op_vt_column(int32_t t);
 int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi,
                             const void* vtlo, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
                             int32_t Tp, void* stream);
+/* The form loco_forward runs: the relative-position table qp[b, head, i, 0..319] = q_scaled[i] . pe_k^T * pe_scale is computed by the
+ * attention kernel itself (each wave for its own 32 queries) from pe_k as fp16 hi/lo planes [320][64] -- no table GEMM in front
+ * of it -- into qp_scratch ([B,12,T,320] fp32: written and read back by the launch; holds the table afterwards). */
+int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
+                               const void* pe_hi, const void* pe_lo, float pe_scale, float* qp_scratch, const int32_t* frames,
+                               float* ctx, int32_t B, int32_t T, int32_t Tp, void* stream);
 
 /* ---- intent head: the first consumer of the embeddings ("next" row f-1) --------------------------------------
  * IntentClassifier (/root/reference/speech_text/intent_classifier.py:24-49): pooling over time

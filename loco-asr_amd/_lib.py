@@ -87,6 +87,7 @@ SIGNATURES = {
     "loco_op_permute_conv_k": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "loco_op_conv_gemm_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp]),
     "loco_op_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "loco_op_attention_f16x3_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "loco_head_last_error": (C.c_char_p, []),
     "loco_head_create": (_vp, [C.c_int]),
     "loco_head_destroy": (None, [_vp]),

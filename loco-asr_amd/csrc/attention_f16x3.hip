@@ -92,13 +92,21 @@ __device__ float* g_attn_dbg = nullptr;  // [workgroup][thread][tile < 8][8 floa
 #define AX_DBG(tile_, code_, S0_, S1_) {}
 #endif
 
-template <bool OUT_SPLIT>
+// TABLE: the relative-position table Qp[b, head, i, 0..319] = q_scaled[i] . pe_k^T (HF modeling:432-441, 939-945) is computed HERE,
+// by the wave that owns query i, instead of by a GEMM launch in front of this kernel: ten 32x32 blocks of Qp^T = pe_k Q^T on the
+// Q fragments already in registers (120 MFMAs per wave: what the table GEMM spent), written to the same [B,12,T,320] buffer and
+// read back by the band tiles exactly as before -- the SAME WAVE reads what it wrote, so no other workgroup is involved.  What
+// moves is the cost: 884 MB of fp32 stores per launch at 30 s x 32 used to be an HBM-bound kernel of its own (2.9 ms per step, nothing
+// else on the chip); issued from here they drain under the MFMA / exp work of 2 048 other waves.
+template <bool OUT_SPLIT, bool TABLE>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16* __restrict__ qhi, const _Float16* __restrict__ qlo,
                                                                  const _Float16* __restrict__ khi, const _Float16* __restrict__ klo,
                                                                  const _Float16* __restrict__ vthi, const _Float16* __restrict__ vtlo,
-                                                                 const float* __restrict__ qp, const int32_t* __restrict__ frames,
+                                                                 float* qp, const int32_t* __restrict__ frames,
                                                                  _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
-                                                                 float* __restrict__ ctx, int T, int Tp, int nqb) {
+                                                                 float* __restrict__ ctx, int T, int Tp, int nqb,
+                                                                 const _Float16* __restrict__ pe_hi, const _Float16* __restrict__ pe_lo,
+                                                                 float pe_scale) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * AX_STG];  // K ring (2 tiles), V^T ring (2 tiles)
     __shared__ float bias_stage[4][32 * 17];
 
@@ -138,9 +146,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             ql[ks] = *reinterpret_cast<const h8*>(qlo + qo + 16 * ks);
         }
     }
-    const float* qprow = qp + (((long)b * kHeads + head) * T + iqc) * kRelN;
-    const float c_past = qprow[kRelN - 1];  // i - j >= 159
-    const float c_future = qprow[0];        // i - j <= -160
+    float* qprow = qp + (((long)b * kHeads + head) * T + iqc) * kRelN;
 
     // LDS-DMA descriptors: one wave instruction writes 1 KiB = 8 rows x 8 pieces of 16 bytes; lane -> row lane/8, stored
     // position lane%8, which holds source piece position ^ swz(row), swz(row) = {row bit 4, row bit 3, row bit 1}.
@@ -300,6 +306,63 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         const int t1 = ntiles > 1 ? 1 : 0;
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) AX_DMA_PIECE(pc, t1, 0, 1, 0)
+    }
+    float c_past, c_future;  // Qp[i][319] (i - j >= 159) and Qp[i][0] (i - j <= -160): the bias of every key beyond the band
+    if (TABLE) {
+        // Qp^T block blk = pe_k[32 blk .. 32 blk + 31] Q^T: A = pe_k rows (fragment of lane (r, h) at k-step ks: pe_k[32 blk + r][16 ks + 8 h ..
+        // + 7], straight from global memory -- 80 KiB of planes that every workgroup reads: L2 / L1 resident), B = the Q fragments.
+        // acc[e] = Qp[iq][32 blk + (e & 3) + 8 (e >> 2) + 4 h]: four consecutive table entries per e >> 2 -> one 16-byte store.
+        // The weight planes carry pe_k * 2^k (loco_api.hip, make_split): pe_scale = 2^-k restores it, exactly.
+        float cf = 0.f, cp = 0.f;
+        // pe_k fragments of block blk + 1 are fetched while block blk multiplies (two register sets, the loop fully unrolled)
+        h8 fh[2][4], fl[2][4];
+        const long po0 = (long)r * kHeadDim + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fh[0][ks] = *reinterpret_cast<const h8*>(pe_hi + po0 + 16 * ks);
+            fl[0][ks] = *reinterpret_cast<const h8*>(pe_lo + po0 + 16 * ks);
+        }
+#pragma unroll
+        for (int blk = 0; blk < kRelN / 32; ++blk) {
+            if (blk + 1 < kRelN / 32) {
+                const long po = po0 + (long)(32 * (blk + 1)) * kHeadDim;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    fh[(blk + 1) & 1][ks] = *reinterpret_cast<const h8*>(pe_hi + po + 16 * ks);
+                    fl[(blk + 1) & 1][ks] = *reinterpret_cast<const h8*>(pe_lo + po + 16 * ks);
+                }
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                acc = AX_MFMA(fl[blk & 1][ks], qh[ks], acc);
+                acc = AX_MFMA(fh[blk & 1][ks], ql[ks], acc);
+                acc = AX_MFMA(fh[blk & 1][ks], qh[ks], acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] *= pe_scale;
+            if (blk == 0) cf = acc[0];                    // table column 0: lane half 0
+            if (blk == kRelN / 32 - 1) cp = acc[15];      // table column 319 = 288 + 3 + 24 + 4: lane half 1
+            if (iq < T) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<float4*>(qprow + 32 * blk + 8 * g4 + 4 * h) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+            }
+        }
+        // both lane halves of a query need both constants: one swap each (after it the first register holds the lower half's
+        // value in both halves, the second the upper half's -- see the row maximum below for why this is inline asm)
+        float cf2 = cf, cp2 = cp;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(cf), "+v"(cf2));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(cp2), "+v"(cp));
+        c_future = cf;  // lower half's
+        c_past = cp;    // upper half's
+        // the band tiles of THIS wave read these rows back (other lanes of it): the stores must have reached L2 first -- the
+        // vmcnt(0) right below, which also retires the first K / V^T tiles' DMAs that were in flight during all of the above
+    } else {
+        c_past = qprow[kRelN - 1];
+        c_future = qprow[0];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -489,18 +552,23 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
 
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
-                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s) {
+                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s,
+                                  const _Float16* pe_hi, const _Float16* pe_lo, float pe_scale) {
     if (B <= 0 || T <= 0 || B > 65535 || Tp < T || (Tp % AX_BK) != 0) return hipErrorInvalidValue;
     const int nqb = (T + AX_BQ - 1) / AX_BQ;
     const long nblk = (long)nqb * kHeads * B;
     if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblk);
-    if (ctx_hi)
-        hipLaunchKernelGGL(attention_f16x3_kernel<true>, grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qp, frames, ctx_hi, ctx_lo,
-                           ctx, T, Tp, nqb);
-    else
-        hipLaunchKernelGGL(attention_f16x3_kernel<false>, grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qp, frames, ctx_hi, ctx_lo,
-                           ctx, T, Tp, nqb);
+    float* qpw = const_cast<float*>(qp);  // written only in the pe_hi != nullptr form (the table is then an output / scratch of this launch)
+    if ((pe_hi == nullptr) != (pe_lo == nullptr)) return hipErrorInvalidValue;
+#define AX_LAUNCH(SPLIT_, TABLE_)                                                                                                      \
+    hipLaunchKernelGGL((attention_f16x3_kernel<SPLIT_, TABLE_>), grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qpw, frames, ctx_hi, \
+                       ctx_lo, ctx, T, Tp, nqb, pe_hi, pe_lo, pe_scale)
+    if (ctx_hi && pe_hi) AX_LAUNCH(true, true);
+    else if (ctx_hi) AX_LAUNCH(true, false);
+    else if (pe_hi) AX_LAUNCH(false, true);
+    else AX_LAUNCH(false, false);
+#undef AX_LAUNCH
     return hipGetLastError();
 }
 

@@ -708,17 +708,16 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
             dbg_check(e, s, "v^T planes hi", l, scat.Vthi, (size_t)B * kHidden * Tp, true, Tp);
             dbg_check(e, s, "v^T planes lo", l, scat.Vtlo, (size_t)B * kHidden * Tp, true, Tp);
         }
-        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320]
-        if ((rc = run_gemm_split(e, c, s, qshi, qslo, kHidden, e->pe_s, kHeadDim, nullptr, nullptr, 0, qp, nullptr, nullptr, kRelN, T, kRelN,
-                                 kHeadDim, kEpiNone, B, (long)T * kHidden, (long)kHeads * T * kRelN, kHeads, kHeadDim, (long)T * kRelN,
-                                 nullptr, nullptr, nullptr, nullptr, K_QP)))
-            return rc;
-        dbg_check(e, s, "relative-position table Qp", l, qp, (size_t)M * kHeads * kRelN, false, kRelN);
+        // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320] is computed INSIDE the attention kernel (attention_f16x3.hip,
+        // TABLE form): `qp` is scratch of that launch; no table GEMM runs any more.
         {
             const double tt = (double)T * T;
-            Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim, 4.0 * (M * (double)(kQkv + kHidden) + M * (double)kHeads * kRelN));
+            // algorithmic FLOPs: QK^T + PV (4 T^2 64 per head) + the compact relative-position table (2 T 320 64 per head);
+            // algorithmic bytes: q|k|v in, context out -- the table is now an internal scratch of the launch, not compulsory traffic
+            Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim + 2.0 * M * (double)kHeads * kRelN * kHeadDim,
+                       4.0 * (M * (double)(kQkv + kHidden)));
             HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
-                                           Tp, s));
+                                           Tp, s, e->pe_s.hi, e->pe_s.lo, e->pe_s.inv_scale));
         }
         if (e->debug_nonfinite) {
             dbg_check(e, s, "attention context planes hi", l, chi, (size_t)M * kHidden, true, kHidden);
@@ -1577,6 +1576,17 @@ int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, c
     HIP_TRY(launch_attention_f16x3((const _Float16*)qhi, (const _Float16*)qlo, (const _Float16*)khi, (const _Float16*)klo,
                                    (const _Float16*)vthi, (const _Float16*)vtlo, qp, frames, nullptr, nullptr, ctx, B, T, Tp,
                                    (hipStream_t)stream));
+    return LOCO_OK;
+}
+
+int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
+                               const void* pe_hi, const void* pe_lo, float pe_scale, float* qp_scratch, const int32_t* frames, float* ctx,
+                               int32_t B, int32_t T, int32_t Tp, void* stream) {
+    if (!qhi || !qlo || !khi || !klo || !vthi || !vtlo || !pe_hi || !pe_lo || !qp_scratch || !ctx)
+        return fail(LOCO_E_INVALID, "loco_op_attention_f16x3_pe: null argument");
+    HIP_TRY(launch_attention_f16x3((const _Float16*)qhi, (const _Float16*)qlo, (const _Float16*)khi, (const _Float16*)klo,
+                                   (const _Float16*)vthi, (const _Float16*)vtlo, qp_scratch, frames, nullptr, nullptr, ctx, B, T, Tp,
+                                   (hipStream_t)stream, (const _Float16*)pe_hi, (const _Float16*)pe_lo, pe_scale));
     return LOCO_OK;
 }
 

@@ -109,7 +109,10 @@ hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, i
 hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s);
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
                                   const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
-                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s);
+                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s,
+                                  const _Float16* pe_hi = nullptr, const _Float16* pe_lo = nullptr, float pe_scale = 1.0f);
+// pe_hi / pe_lo != nullptr: the relative-position table is COMPUTED by the kernel (Qp = q . pe_k^T * pe_scale, pe planes [320][64])
+// into `qp`, which is then scratch of the launch ([B,12,T,320] fp32) instead of an input.
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
 void reload_gemm_knobs();  // re-read the LOCO_GEMM_* A/B knobs from the environment (gemm_f16x3.hip)
 // hi/lo planes of x * scale (scale a power of two)

@@ -304,6 +304,43 @@ def test_attention_core_f16x3(B, T, frames, oracle):
     assert rel_l2(ctx, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,T,frames", [(2, 249, [249, 162]), (1, 1499, None), (3, 700, [700, 333, 64])])
+def test_attention_f16x3_computes_the_relative_position_table_itself(B, T, frames, oracle):
+    """The form loco_forward runs (round 3): no table GEMM in front of attention -- every wave computes Qp = q . pe_k^T for its own 32
+    queries (ten 32x32 MFMA blocks on the Q fragments it holds), writes it to the scratch table and reads the band back.  Against the
+    fp64 oracle on the same hi+lo operands, against the external-table form of the same kernel, and the scratch must hold the table
+    (pe planes scaled by 2^9 with pe_scale 2^-9, as loco_finalize_weights stores them)."""
+    qkv = hu("att.qkv", (B, T, 2304), 1.5)
+    qkv[..., :768] *= 0.125 * 1.5
+    pe_k = hu("att.pe", (320, 64), 0.9)
+    q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
+    k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
+    v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
+    Tp = (T + 63) // 64 * 64
+    qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
+    kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
+    vt = torch.zeros(B, 768, Tp)
+    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
+    vt[:, :, col[:T]] = qkv[..., 1536:].transpose(1, 2)
+    vh, vl = planes(vt.reshape(B * 768, Tp))
+    ph, pl_ = planes(pe_k * 512.0)
+    fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
+    frd = fr.cuda() if fr is not None else None
+    scratch = torch.full((B, 12, T, 320), float("nan"), device="cuda")
+    ctx = torch.empty(B, T, 768, device="cuda")
+    check(lib().loco_op_attention_f16x3_pe(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(ph), ptr(pl_), 1.0 / 512.0, ptr(scratch),
+                                           ptr(frd), ptr(ctx), B, T, Tp, stream()))
+    # the operands the kernel really multiplies: q and pe_k as their hi + lo planes
+    qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2).cpu()
+    ped = ((ph.double() + pl_.double()) / 512.0).cpu()
+    assert rel_l2(scratch, qd @ ped.t()) < 2e-6
+    ref = oracle.attention_core(qd, k.double(), v.double(), ped, None if fr is None else fr.long(), q_block=128).transpose(1, 2).reshape(B, T, 768)
+    assert bool(torch.isfinite(ctx).all()) and rel_l2(ctx, ref) < 1e-5
+    ctx2 = torch.empty_like(ctx)
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(scratch), ptr(frd), ptr(ctx2), B, T, Tp, stream()))
+    assert torch.equal(ctx, ctx2)  # same table, same kernel body: the two forms agree bit for bit
+
+
 @pytest.mark.parametrize("key,gap", [(7, 30.0), (101, 30.0), (7, 80.0), (205, 14.0)])
 def test_attention_f16x3_row_max_covers_both_lane_halves(key, gap, oracle):
     """Regression (round 3): each query's 64 keys of a tile sit in TWO lane halves (keys {0-3, 8-11, ...} / {4-7, 12-15, ...}); the
