@@ -21,3 +21,12 @@ python3 tools/pmc_traffic.py gemm_f16x3_dma_kernel $(ls $O/pmc_FETCH_SIZE/*/*cou
   --exclude "<0, false, 2, 2, 2," --exclude "<4, false, 8, 1," --workload 30sx32
 python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc_WRITE_SIZE/*/*counter_collection.csv) $O/attention_f16x3_traffic.json --workload 30sx32
 cp $(ls $O/stats/*/*kernel_stats.csv) $O/kernel_stats.csv
+# 10 min x 4: PMC traffic of the attention kernel at that shape (bench.py keys roofline.traffic by workload)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc10_$c --output-format csv -- python3 bench.py --clip-seconds 600 --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams > $O/pmc10_$c.log 2>&1 || exit 1
+  echo "pmc 10min $c done"
+done
+python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc10_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc10_WRITE_SIZE/*/*counter_collection.csv) $O/attention_f16x3_traffic_10minx4.json --workload 10minx4
+python3 tools/pmc_traffic.py gemm_f16x3_dma_kernel $(ls $O/pmc10_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc10_WRITE_SIZE/*/*counter_collection.csv) $O/gemm_f16x3_traffic_10minx4.json --exclude "<4, false, 8, 1," --workload 10minx4
+find $O -name "*kernel_trace.csv" -size +20M -delete
+find $O -name "*counter_collection.csv" -size +30M -delete
