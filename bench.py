@@ -43,6 +43,10 @@ CLIP_SECONDS = 30
 BATCH_PER_GPU = 32
 PEAK_F32_MFMA_TFLOPS = 157.3   # dense fp32-input MFMA, MI355X_MICROARCH.md
 PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA (the 5 PF headline includes 2:1 sparsity)
+# What a register-resident loop of nothing but fp16 MFMAs reaches on RANDOM operands on this part: the socket power limit holds the
+# clock at ~1.7 GHz (tools/mfma_probe/, profiles/r03_mfma_energy_probe.txt; 2 265-2 480 on all-zero operands).  Reported beside the
+# contractual peak, never instead of it.
+PRACTICAL_F16_MFMA_TFLOPS_RANDOM_OPERANDS = 1640.0
 # profiling bucket (loco_api.hip kKernelNames) -> (kernel symbol, bound, peak, MFMAs issued per algorithmic product)
 BUCKETS = {"gemm_f32": ("gemm_f32_kernel", "mfma", PEAK_F32_MFMA_TFLOPS, 1),
            "attention_f32": ("attention_kernel", "mfma", PEAK_F32_MFMA_TFLOPS, 1),
@@ -120,6 +124,8 @@ def make_roofline(by, precision, steps, workload_key="30sx32"):
         r["mfma_flops_issued_per_algorithmic_flop"] = mfma_per_product
         r["mfma_issued_tflops"] = round(ach * mfma_per_product, 1)
         r["mfma_issued_frac_of_peak"] = round(ach * mfma_per_product / peak, 4)
+        r["practical_peak_random_operands_tflops"] = PRACTICAL_F16_MFMA_TFLOPS_RANDOM_OPERANDS
+        r["mfma_issued_frac_of_practical_peak"] = round(ach * mfma_per_product / PRACTICAL_F16_MFMA_TFLOPS_RANDOM_OPERANDS, 4)
     return r
 
 
