@@ -83,13 +83,31 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
         gw[q] = W + (long)rw * p.ldw + sk;
     }
 
-    f32x16 acc[2][2];
+    // BLOCKED ACCUMULATION (round 3).  One v_mfma_f32_32x32x2_f32 adds two products to its accumulator, so a dot product over K is a
+    // chain of K/2 roundings -- 384 for K = 768, 1 536 for the second feed-forward GEMM -- where a CPU GEMM's vector lanes and
+    // unrolled partial sums make it a tree.  On well-conditioned models nobody sees the difference; on the outlier-channel weight
+    // family (golden g10) this mode was 2-4x torch's fp32 error per layer and 2e-4 of HF-in-float64 by layer 7 -- the "exact"
+    // fallback less accurate than the default split mode it backs up.  Every four k-tiles the running block sum `acc` is folded into
+    // `tot` (64 vector adds per lane) and restarted: chains of 64 roundings per block and K / 128 block sums.  g10: 2.0e-4 -> 1.0e-4
+    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the 256
+    // registers of the two-workgroups-per-CU form (eight of the staging registers spill inside the loop) -- this mode's GEMM goes from
+    // 0.80 to 0.74 of the fp32 MFMA peak (104 -> 113 ms per 30 s x 32 step).  It is the accuracy fallback: accuracy wins.  (Folding
+    // every eight k-tiles instead costs the same registers and gave 1.14e-4 / 6.2e-5.)
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+#define LOCO_FLUSH_ACC(every_)                                                                  \
+    if (((kt + 1) & ((every_) - 1)) == 0 && kt + 1 < nk) {                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                  \
+                tot[i_][j_] += acc[i_][j_];                                                     \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) acc[i_][j_][e_] = 0.f;        \
+            }                                                                                   \
+    }
 
     f32x4 ra4[4], rw4[4];
 #pragma unroll
@@ -178,6 +196,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
         __builtin_amdgcn_sched_barrier(0);                                                      \
         LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                      \
+        LOCO_FLUSH_ACC(4)                                                                       \
     }
 
     // Software pipeline (see header): global loads two k-tiles ahead (two register sets, loop unrolled by 2),
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
                 if (n < p.N) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    for (int e = 0; e < 4; ++e) v[e] = tot[i][j][4 * g + e] + acc[i][j][4 * g + e];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (EPI == kEpiGelu) {
 #pragma unroll
@@ -256,13 +275,31 @@ __global__ __launch_bounds__(kGemmThreads, 3) void gemm_f32_bk16_kernel(GemmArgs
         gw[q] = W + (long)rw * p.ldw + sk;
     }
 
-    f32x16 acc[2][2];
+    // BLOCKED ACCUMULATION (round 3).  One v_mfma_f32_32x32x2_f32 adds two products to its accumulator, so a dot product over K is a
+    // chain of K/2 roundings -- 384 for K = 768, 1 536 for the second feed-forward GEMM -- where a CPU GEMM's vector lanes and
+    // unrolled partial sums make it a tree.  On well-conditioned models nobody sees the difference; on the outlier-channel weight
+    // family (golden g10) this mode was 2-4x torch's fp32 error per layer and 2e-4 of HF-in-float64 by layer 7 -- the "exact"
+    // fallback less accurate than the default split mode it backs up.  Every four k-tiles the running block sum `acc` is folded into
+    // `tot` (64 vector adds per lane) and restarted: chains of 64 roundings per block and K / 128 block sums.  g10: 2.0e-4 -> 1.0e-4
+    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the 256
+    // registers of the two-workgroups-per-CU form (eight of the staging registers spill inside the loop) -- this mode's GEMM goes from
+    // 0.80 to 0.74 of the fp32 MFMA peak (104 -> 113 ms per 30 s x 32 step).  It is the accuracy fallback: accuracy wins.  (Folding
+    // every eight k-tiles instead costs the same registers and gave 1.14e-4 / 6.2e-5.)
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
+#define LOCO_FLUSH_ACC(every_)                                                                  \
+    if (((kt + 1) & ((every_) - 1)) == 0 && kt + 1 < nk) {                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
+            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                  \
+                tot[i_][j_] += acc[i_][j_];                                                     \
+                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) acc[i_][j_][e_] = 0.f;        \
+            }                                                                                   \
+    }
 
     f32x4 ra4[2], rw4[2];
 #pragma unroll
@@ -343,6 +380,7 @@ __global__ __launch_bounds__(kGemmThreads, 3) void gemm_f32_bk16_kernel(GemmArgs
         __builtin_amdgcn_sched_barrier(0);                                                      \
         LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                      \
+        /* no block flush in this three-workgroups-per-CU form: it has 168 registers per lane and a second accumulator set spills */ \
     }
 
     // Software pipeline (see header): global loads two k-tiles ahead (two register sets, loop unrolled by 2),
@@ -377,7 +415,7 @@ __global__ __launch_bounds__(kGemmThreads, 3) void gemm_f32_bk16_kernel(GemmArgs
                 if (n < p.N) {
                     f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    for (int e = 0; e < 4; ++e) v[e] = tot[i][j][4 * g + e] + acc[i][j][4 * g + e];
                     if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
                     if (EPI == kEpiGelu) {
 #pragma unroll
