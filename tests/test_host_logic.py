@@ -319,3 +319,21 @@ def test_loader_threads_resample_on_the_ranks_own_gpu(monkeypatch, tmp_path):
     with ThreadPoolExecutor(2) as pool:
         y = list(pool.map(lambda _: extract.load_audio_16k(path, rank_device), range(3)))
     assert len(y) == 3 and seen == [(8000, rank_device, 8000)] * 3
+
+
+def test_train_head_batch_dealing_partitions_every_epoch_and_the_validation_set():
+    """Data-parallel head training (configs[4]): every rank draws the SAME epoch permutation and takes batches rank, rank + W, ...
+    (an incomplete last round is dropped so that the gradient all-reduces line up); validation batches are dealt the same way and
+    the two sums meet in one all-reduce.  Together the ranks' shares must tile the data exactly once."""
+    th = importlib.import_module("loco-asr_amd.train_head")
+    n, bs, W = 103, 16, 4
+    seen = []
+    for rank in range(W):
+        g = torch.Generator().manual_seed(0)
+        ids, batches = th.epoch_batches(n, bs, W, rank, g)
+        assert ids == list(range(rank, (7 // W) * W, W))  # 7 batches -> one full round of 4
+        seen += [i for b in batches for i in b]
+    assert len(seen) == len(set(seen)) == 4 * 16
+    val = [i for rank in range(W) for b in th.strided_batches(n, bs, W, rank) for i in b]
+    assert sorted(val) == list(range(n))
+    assert th.strided_batches(n, bs, 1, 0) == [list(range(a, min(n, a + bs))) for a in range(0, n, bs)]
