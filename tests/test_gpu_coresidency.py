@@ -45,6 +45,10 @@ def beside_attention(launch, out, trials=4, reps_attention=10, reps_victim=3):
     """launch(stream) enqueues the victim kernel writing `out`; returns the number of trials whose output differs from the solo run."""
     att = Attention()
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    # the victim's inputs (and the aggressor's) were produced on the DEFAULT stream; sa / sb are not ordered behind it.  Without this
+    # synchronisation the solo reference run could read a 589 MB input that torch.randn was still filling -- a sporadic 4-of-4
+    # "miscompare" of this test itself (seen once in round 3, in one full-suite run of three), not of the kernels.
+    torch.cuda.synchronize()
     launch(sa)
     torch.cuda.synchronize()
     ref = out.clone()
@@ -56,7 +60,14 @@ def beside_attention(launch, out, trials=4, reps_attention=10, reps_victim=3):
         for _ in range(reps_victim):
             launch(sa)
         torch.cuda.synchronize()
-        bad += 0 if torch.equal(out, ref) else 1
+        if not torch.equal(out, ref):
+            bad += 1
+            d = (out != ref).reshape(out.shape[0], -1) if out.dim() > 1 else (out != ref)[None]
+            idx = d.nonzero()[:6].tolist()
+            o2, r2 = out.reshape(d.shape), ref.reshape(d.shape)
+            print(f"co-residency miscompare: {int(d.sum())} elements in {int(d.any(1).sum())} rows differ; first: "
+                  + "; ".join(f"[{a},{b}] got {float(o2[a, b])!r} expected {float(r2[a, b])!r}" for a, b in idx)
+                  + f"; columns hit: {d.any(0).nonzero().flatten()[:24].tolist()}")
     return bad
 
 

@@ -368,17 +368,21 @@ def test_concurrent_forwards_on_two_user_streams_are_bit_identical():
         wss = [torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)]
         out = torch.empty(B, T, 768, device="cuda")
         streams = [torch.cuda.Stream() for _ in range(2)]
+        # forwards of one handle that overlap go through loco_forward_async, each with its own status block (include/loco_asr.h:
+        # loco_forward keeps its status in the handle and must not overlap with itself)
+        stat = [torch.zeros(int(L_.loco_status_bytes()), dtype=torch.uint8).pin_memory() for _ in range(2)]
         for trial in range(8):
             out.zero_()
             torch.cuda.synchronize()
             for _ in range(3):
                 for i in range(2):
                     a, b = i * (B // 2), (i + 1) * (B // 2)
-                    rc = L_.loco_forward(h, C.c_void_p(xs[a:b].data_ptr()), C.c_void_p(ms[a:b].data_ptr()), b - a, L,
-                                         C.c_void_p(out[a:b].data_ptr()), None, None, C.c_void_p(wss[i].data_ptr()), need,
-                                         C.c_void_p(streams[i].cuda_stream))
+                    rc = L_.loco_forward_async(h, -1, C.c_void_p(xs[a:b].data_ptr()), C.c_void_p(ms[a:b].data_ptr()), b - a, L,
+                                               C.c_void_p(out[a:b].data_ptr()), None, None, C.c_void_p(wss[i].data_ptr()), need,
+                                               C.c_void_p(streams[i].cuda_stream), C.c_void_p(stat[i].data_ptr()))
                     assert rc == 0, L_.loco_last_error()
             torch.cuda.synchronize()
+            assert all(L_.loco_status_check(C.c_void_p(st_.data_ptr()), None, 0) == 0 for st_ in stat)
             bad = [i for i in range(B) if not torch.equal(out[i], ref[i])]
             assert not bad, (trial, bad)
     finally:

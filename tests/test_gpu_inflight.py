@@ -121,6 +121,7 @@ def test_enqueue_from_two_host_threads():
             B, L = x.shape
             T = int(lib.loco_output_frames(L))
             st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())  # a32 was produced on this thread's current (default) stream
             ws = torch.empty(int(lib.loco_workspace_bytes(enc._handle, B, L)), dtype=torch.uint8, device="cuda")
             status = torch.zeros(nst, dtype=torch.uint8).pin_memory()
             outs = []
