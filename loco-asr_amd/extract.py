@@ -288,7 +288,10 @@ def main(argv=None):
         clips = [fetch(i) for i in idx]
         if any(torch.is_tensor(c) for c in clips):  # some files were resampled on the device: the whole batch is padded there
             clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
-        return idx, processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        feats = processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        # the H2D copies are enqueued HERE, by the loader thread (pinned source, non-blocking, the default stream): the thread that
+        # enqueues forwards only waits for the future; forward_async orders its stream behind the default stream
+        return idx, feats.to(device)
 
     def on_device(_device=device):  # loader threads start on GPU 0: select the rank's GPU for anything they do there
         torch.cuda.set_device(_device)
@@ -354,25 +357,38 @@ def main(argv=None):
         if consumer:
             consumer.start()
         try:
+            prof = [0.0] * 4 if os.environ.get("LOCO_EXTRACT_PROFILE") == "1" else None  # seconds: wait for the staged batch, H2D, enqueue, hand-over
+            tick = time.perf_counter
             for rnd in range(n_rounds):
                 if failure:
                     break
+                t_a = tick()
                 if pool:
                     idx, feats = pending.pop(0).result()
                     if rnd + ahead < n_rounds:
                         pending.append(pool.submit(host_batch, rnd + ahead))
                 else:
                     idx, feats = host_batch(rnd)
+                t_b = tick()
                 if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
                     item = (idx, None)
-                elif inflight > 1:
-                    item = (idx, encoder.forward_async(**feats.to(device)))
+                    t_c = t_b
                 else:
-                    item = (idx, encoder(**feats.to(device)))
+                    on_dev = feats if feats["input_values"].is_cuda else feats.to(device)
+                    t_c = tick()
+                    item = (idx, encoder.forward_async(**on_dev) if inflight > 1 else encoder(**on_dev))
+                t_d = tick()
                 if consumer:
                     todo.put(item)
                 else:
                     finish(item[0], item[1].last_hidden_state if item[1] is not None else empty)
+                if prof is not None:
+                    t_e = tick()
+                    for k_, v_ in enumerate((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)):
+                        prof[k_] += v_
+            if prof is not None:
+                print("main thread, ms per batch: wait for the staged batch %.3f, H2D %.3f, enqueue %.3f, hand-over / finish %.3f"
+                      % tuple(1e3 * v_ / max(1, n_rounds) for v_ in prof))
         finally:
             if consumer:
                 todo.put(None)
