@@ -7,7 +7,8 @@
  * manifest.txt: one line per tensor "<hf key> <ndim> <d0> [<d1> ...]" in the order the fp32 data appear in weights.bin
  * (keys exactly as `prenet.*` / `wrapped_encoder.*` of the reference's two state dicts, include/loco_asr.h).
  * wave.f32: B*L fp32 samples; out.f32 receives B*T*768 fp32 embeddings.  tests/test_gpu_cabi_c.py builds and runs this
- * and compares the file with what the Python wrapper returns (bit for bit: it is the same library call).
+ * and compares the file with what the Python wrapper returns (bit for bit: it is the same library call).  The second half shows
+ * loco_forward_async: three forwards of the one handle in flight on three streams, each with its own workspace and status block.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -80,6 +81,32 @@ int main(int argc, char** argv) {
     fclose(fo);
     printf("encoded %d x %ld samples -> [%d, %ld, 768], workspace %.1f MB%s\n", B, L, B, T, wsb / 1e6,
            used_fp32 ? " (re-run on the exact-fp32 kernels: activation range)" : "");
+
+    /* ---- several forwards of the same handle in flight (the reference's batch-of-two loop at GPU speed): each forward owns a
+     * stream, a workspace and a status block; loco_forward_async keeps nothing of a forward in the handle.  Here the same batch is
+     * encoded NF times concurrently and every copy must equal the one above bit for bit. */
+    enum { NF = 3 };
+    hipStream_t st[NF];
+    void* wsk[NF];
+    float* outk[NF];
+    void* status[NF];
+    for (int k = 0; k < NF; ++k) {
+        CHECK_HIP(hipStreamCreate(&st[k]));
+        CHECK_HIP(hipMalloc(&wsk[k], wsb));
+        CHECK_HIP(hipMalloc((void**)&outk[k], nout * sizeof(float)));
+        CHECK_HIP(hipHostMalloc(&status[k], loco_status_bytes(), hipHostMallocDefault)); /* pinned: the status copy stays asynchronous */
+    }
+    for (int k = 0; k < NF; ++k)  /* enqueue all of them before waiting for any */
+        CHECK_LOCO(loco_forward_async(enc, -1, dwav, NULL, B, L, outk[k], NULL, NULL, wsk[k], wsb, st[k], status[k]));
+    float* hk = (float*)malloc(nout * sizeof(float));
+    int same = 0;
+    for (int k = 0; k < NF; ++k) {
+        CHECK_HIP(hipStreamSynchronize(st[k]));
+        CHECK_LOCO(loco_status_check(status[k], NULL, 0)); /* LOCO_E_RANGE here = re-run THIS batch with precision 0 */
+        CHECK_HIP(hipMemcpy(hk, outk[k], nout * sizeof(float), hipMemcpyDeviceToHost));
+        same += memcmp(hk, hout, nout * sizeof(float)) == 0;
+    }
+    printf("%d forwards in flight on %d streams: %d of %d bit-identical to the single forward\n", NF, NF, same, NF);
     loco_destroy(enc);
-    return 0;
+    return same == NF ? 0 : 4;
 }

@@ -188,10 +188,12 @@ def main(argv=None):
                     help="-m text: name or local directory of the SpeechT5 tokenizer (the reference's processor, …base…py:38)")
     ap.add_argument("--format", choices=["pickle", "npy"], default="pickle")
     ap.add_argument("--gather", action="store_true", help="all-gather embeddings so that rank 0 writes everything")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight on the GPU at once (each on its own stream / workspace / status block).  The batches "
                          "themselves are untouched -- the reference's pairs in corpus order -- and so are the results, bit for bit; "
-                         "a pair of 5 s clips alone cannot fill 256 CUs.  1 = one batch at a time, as the reference runs")
+                         "a pair of 5 s clips alone cannot fill 256 CUs.  1 = one batch at a time, as the reference runs; 0 (default) = "
+                         "4 for utterances, 1 for --window-seconds >= 60 (a pair of 10-minute windows fills the chip by itself and "
+                         "every slot would hold a 15 GB workspace)")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
@@ -297,7 +299,7 @@ def main(argv=None):
         torch.cuda.set_device(_device)
 
     from concurrent.futures import ThreadPoolExecutor
-    inflight = max(1, args.inflight)
+    inflight = args.inflight if args.inflight > 0 else (1 if args.window_seconds >= 60 else 4)
     # the window cache of one decoded recording is not thread-safe: windows are prepared by ONE thread, in order
     n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
     pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None

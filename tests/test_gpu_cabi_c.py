@@ -43,3 +43,4 @@ def test_c_host_reproduces_the_python_wrapper(tmp_path):
     rel = np.linalg.norm(got.astype(np.float64) - ref) / np.linalg.norm(ref)
     assert rel < 2e-6, rel
     assert "workspace" in res.stdout
+    assert "3 forwards in flight on 3 streams: 3 of 3 bit-identical" in res.stdout, res.stdout
