@@ -332,6 +332,21 @@ def test_c_abi_error_codes():
     assert L_.loco_forward(h, ptr(x), None, 0, 16000, ptr(out), None, None, ptr(ws), need, stream()) < 0
     assert L_.loco_forward(h, ptr(x), None, 2, 399, ptr(out), None, None, ptr(ws), need, stream()) < 0
     assert L_.loco_workspace_bytes(h, 2, 399) == 0 and L_.loco_output_frames(399) == 0 and L_.loco_output_frames(400) == 1
+    # loco_forward_async: a status block is mandatory and 8-byte aligned, the precision argument is -1 or a documented mode, and a
+    # failed enqueue leaves the block invalid (loco_status_check refuses it) rather than describing some earlier forward
+    status = torch.zeros(int(L_.loco_status_bytes()) + 8, dtype=torch.uint8).pin_memory()
+    async_args = lambda prec, ws_bytes, st_ptr: (h, prec, ptr(x), None, 2, 16000, ptr(out), None, None, ptr(ws), ws_bytes, stream(), st_ptr)
+    assert L_.loco_forward_async(*async_args(-1, need, None)) == -1
+    assert L_.loco_forward_async(*async_args(-1, need, C.c_void_p(status.data_ptr() + 4))) == -1 and b"aligned" in L_.loco_last_error()
+    assert L_.loco_forward_async(*async_args(5, need, C.c_void_p(status.data_ptr()))) == -1 and b"f16x2" in L_.loco_last_error()
+    assert L_.loco_forward_async(*async_args(-1, need, C.c_void_p(status.data_ptr()))) == 0
+    torch.cuda.synchronize()
+    assert L_.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) == 0
+    assert L_.loco_forward_async(*async_args(-1, need - 1, C.c_void_p(status.data_ptr()))) == -3  # LOCO_E_WORKSPACE
+    assert L_.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) == -1 and b"status block" in L_.loco_last_error()
+    assert L_.loco_forward_async(*async_args(0, need, C.c_void_p(status.data_ptr()))) == 0  # exact-fp32 mode for this call only
+    torch.cuda.synchronize()
+    assert L_.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) == 0 and L_.loco_get_precision(h) == 1
     # knobs reject values outside their domain
     assert L_.loco_set_streams(h, 3) < 0 and L_.loco_set_streams(h, 2) == 0
     assert L_.loco_set_precision(h, 7) < 0 and L_.loco_set_precision(h, 1) == 0
