@@ -335,7 +335,8 @@ def test_c_abi_error_codes():
     # loco_forward_async: a status block is mandatory and 8-byte aligned, the precision argument is -1 or a documented mode, and a
     # failed enqueue leaves the block invalid (loco_status_check refuses it) rather than describing some earlier forward
     status = torch.zeros(int(L_.loco_status_bytes()) + 8, dtype=torch.uint8).pin_memory()
-    async_args = lambda prec, ws_bytes, st_ptr: (h, prec, ptr(x), None, 2, 16000, ptr(out), None, None, ptr(ws), ws_bytes, stream(), st_ptr)
+    out2 = torch.empty_like(out)  # the checks below must not disturb `out`, which the end of the test compares with
+    async_args = lambda prec, ws_bytes, st_ptr: (h, prec, ptr(x), None, 2, 16000, ptr(out2), None, None, ptr(ws), ws_bytes, stream(), st_ptr)
     assert L_.loco_forward_async(*async_args(-1, need, None)) == -1
     assert L_.loco_forward_async(*async_args(-1, need, C.c_void_p(status.data_ptr() + 4))) == -1 and b"aligned" in L_.loco_last_error()
     assert L_.loco_forward_async(*async_args(5, need, C.c_void_p(status.data_ptr()))) == -1 and b"f16x2" in L_.loco_last_error()
@@ -347,6 +348,7 @@ def test_c_abi_error_codes():
     assert L_.loco_forward_async(*async_args(0, need, C.c_void_p(status.data_ptr()))) == 0  # exact-fp32 mode for this call only
     torch.cuda.synchronize()
     assert L_.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) == 0 and L_.loco_get_precision(h) == 1
+    assert not torch.equal(out2, out) and rel_l2(out2, out) < 1e-5  # another arithmetic, the same embeddings
     # knobs reject values outside their domain
     assert L_.loco_set_streams(h, 3) < 0 and L_.loco_set_streams(h, 2) == 0
     assert L_.loco_set_precision(h, 7) < 0 and L_.loco_set_precision(h, 1) == 0
