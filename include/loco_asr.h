@@ -161,8 +161,9 @@ int loco_forward_checked(loco_encoder* enc, const float* wav, const int32_t* att
  *     the exact-fp32 kernels without switching the handle under the other forwards in flight.
  * Forwards with different (workspace, status, out) triples may be enqueued on different streams and from different host threads
  * at the same time; the handle is only read.  (Exceptions, all one-time or diagnostic: a clip longer than any before grows the
- * sinusoid table -- warm the handle up with the longest length first, or load the table with loco_set_weight; profiling, taps
- * and hidden_states remain single-caller features; the second stream of loco_set_streams is shared, its use is serialised.)
+ * sinusoid table -- under a lock, blocking that one call until the new table is complete, the old table staying alive for the
+ * forwards already enqueued; profiling, taps and hidden_states remain single-caller features; the second stream of
+ * loco_set_streams is shared, its use is serialised.)
  *   loco_status_check   after `stream` has completed the forward: LOCO_OK, or LOCO_E_RANGE with the message naming the first
  *                       stage outside the range (the output must then not be used: re-run the batch with precision 0);
  *                       LOCO_E_INVALID when `status` was not filled by a successful loco_forward_async.

@@ -129,6 +129,8 @@ struct loco_encoder {
     float* sin_tab = nullptr;
     int sin_rows = 0;
     bool sin_user = false;
+    std::mutex sin_mu;            // growth of the sinusoid table (ensure_sin_rows)
+    std::vector<float*> retired;  // tables replaced while forwards may still have been reading them: freed at loco_destroy
     // taps
     float *tap_conv = nullptr, *tap_proj = nullptr, *tap_prenet = nullptr;
     // text front end (SpeechT5TextEncoderPrenet): optional; a handle may carry the speech prenet, the text prenet or both
@@ -434,19 +436,21 @@ int run_copy(loco_encoder* e, hipStream_t s, float* dst, const float* src, size_
 
 int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s) {
     if (e->sin_rows >= rows) return LOCO_OK;
-    // grow (HF does the same on demand, modeling:331-333); happens once per new maximum length
+    // grow (HF does the same on demand, modeling:331-333); happens once per new maximum length.  Safe with other forwards of the handle
+    // in flight: the new table is complete before it is published (this is the one place a forward may block its host thread), and
+    // the old one is RETIRED, not freed -- forwards already enqueued on other streams keep reading it -- until loco_destroy.
+    std::lock_guard<std::mutex> lock(e->sin_mu);
+    if (e->sin_rows >= rows) return LOCO_OK;
     int want = rows < 4002 ? 4002 : rows + 2;
     float* nt = nullptr;
     HIP_TRY(hipMalloc(&nt, (size_t)want * kHidden * sizeof(float)));
     hipError_t err = launch_sinusoid_table(nt, want, s);
+    if (err == hipSuccess) err = hipStreamSynchronize(s);
     if (err != hipSuccess) {
         (void)hipFree(nt);
         return fail(LOCO_E_HIP, "sinusoid table: %s", hipGetErrorString(err));
     }
-    if (e->sin_tab) {
-        HIP_TRY(hipStreamSynchronize(s));
-        (void)hipFree(e->sin_tab);
-    }
+    if (e->sin_tab) e->retired.push_back(e->sin_tab);
     e->sin_tab = nt;
     e->sin_rows = want;
     e->sin_user = false;
@@ -866,6 +870,7 @@ void loco_destroy(loco_encoder* e) {
     (void)hipFree(e->debug_counter);
     if (e->own) (void)hipHostFree(e->own);
     (void)hipFree(e->sin_tab);
+    for (float* t : e->retired) (void)hipFree(t);
     (void)hipFree(e->text_embed);
     (void)hipFree(e->text_alpha);
     (void)hipFree(e->text_pe);

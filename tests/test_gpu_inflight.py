@@ -165,3 +165,50 @@ def test_extract_cli_inflight_writes_identical_pickles(tmp_path):
     with open(os.path.join(outs[4], names[0]), "rb") as fh:
         d = pickle.load(fh)
     assert d["embedding"].dtype == np.float32 and d["embedding"].shape[1] == 768
+
+
+def test_the_sinusoid_table_may_grow_while_other_forwards_are_in_flight():
+    """include/loco_asr.h: a clip longer than any before makes the library grow its sinusoid table (HF does the same on demand,
+    modeling:331-333).  With forwards of the handle in flight on other streams the old table must stay alive for them (it is retired,
+    not freed) and the new one must be complete before it is published.  Raw C ABI on a private one-layer model: eight forwards of a
+    short batch queued on stream A, then -- no synchronisation -- a 4 062-frame clip on stream B whose enqueue grows the table."""
+    import ctypes as C
+    sd = la.synth.encoder_state_dict(0, layers=1)
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    mm = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                          {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=1).cuda()
+    enc = mm.speecht5.encoder
+    lib = enc._lib
+    xs = torch.from_numpy(la.synth.batch([40000, 31000])[0]).cuda()
+    enc(input_values=xs)  # loads the weights; the table has its initial ~4 000 rows
+    xl = torch.from_numpy(la.synth.batch([1_300_000], first_index=3)[0]).cuda()
+    assert int(lib.loco_output_frames(1_300_000)) == 4062
+    nst = int(lib.loco_status_bytes())
+
+    def slot(x):
+        B, L = x.shape
+        return dict(x=x, B=B, L=L, st=torch.cuda.Stream(), ws=torch.empty(int(lib.loco_workspace_bytes(enc._handle, B, L)), dtype=torch.uint8, device="cuda"),
+                    status=torch.zeros(nst, dtype=torch.uint8).pin_memory(),
+                    outs=[torch.empty((B, int(lib.loco_output_frames(L)), 768), device="cuda") for _ in range(8)])
+
+    a, b = slot(xs), slot(xl)
+    torch.cuda.synchronize()
+
+    def enqueue(s, out):
+        rc = lib.loco_forward_async(enc._handle, 1, C.c_void_p(s["x"].data_ptr()), None, s["B"], s["L"], C.c_void_p(out.data_ptr()), None, None,
+                                    C.c_void_p(s["ws"].data_ptr()), s["ws"].numel(), C.c_void_p(s["st"].cuda_stream), C.c_void_p(s["status"].data_ptr()))
+        assert rc == 0, lib.loco_last_error()
+
+    for o in a["outs"]:
+        enqueue(a, o)          # in flight on stream A, reading the small table
+    enqueue(b, b["outs"][0])   # grows the table inside the call
+    torch.cuda.synchronize()
+    assert lib.loco_status_check(C.c_void_p(a["status"].data_ptr()), None, 0) == 0
+    assert lib.loco_status_check(C.c_void_p(b["status"].data_ptr()), None, 0) == 0
+    for o in a["outs"][1:]:
+        assert torch.equal(o, a["outs"][0])
+    # references with the grown table: the same rows hold the same values (one generator), so nothing may have changed
+    enqueue(a, a["outs"][1]); enqueue(b, b["outs"][1])
+    torch.cuda.synchronize()
+    assert torch.equal(a["outs"][1], a["outs"][0]) and torch.equal(b["outs"][1], b["outs"][0])
+    assert bool(torch.isfinite(b["outs"][0]).all())
