@@ -219,6 +219,10 @@ int loco_text_max_positions(const loco_encoder* enc);
 int loco_forward_text(loco_encoder* enc, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T,
                       float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* the text forward with its own status block, as loco_forward_async is to loco_forward (several batches of transcripts in flight) */
+int loco_forward_text_async(loco_encoder* enc, int precision, const int32_t* input_ids, const int32_t* attention_mask, int32_t B,
+                            int32_t T, float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
+                            size_t workspace_bytes, void* stream, void* status);
 
 /* Arithmetic of the contractions (conv layers 1-6, feature projection, positional conv, QKV / out / FFN projections, Qp table,
  * QK^T, PV).  LOCO_PRECISION_MODES lists every mode loco_set_precision accepts (tests/test_cabi_symbols.py keeps the two in step):

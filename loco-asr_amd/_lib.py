@@ -61,6 +61,7 @@ SIGNATURES = {
     "loco_text_max_positions": (C.c_int, [_vp]),
     "loco_forward_text": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp]),
     "loco_precision_name": (C.c_char_p, [C.c_int]),
+    "loco_forward_text_async": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _i32, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
     "loco_set_precision": (C.c_int, [_vp, C.c_int]),
     "loco_get_precision": (C.c_int, [_vp]),
     "loco_set_streams": (C.c_int, [_vp, C.c_int]),

@@ -1352,9 +1352,10 @@ size_t loco_text_workspace_bytes(const loco_encoder* e, int32_t B, int32_t T) {
 
 int loco_text_max_positions(const loco_encoder* e) { return e ? e->text_pe_rows : 0; }
 
-int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T, float* out,
-                      int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!e || !input_ids || !out || !workspace) return fail(LOCO_E_INVALID, "loco_forward_text: null argument");
+namespace {
+int forward_text_impl(loco_encoder* e, int precision, StatusBlock* st, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T,
+                      float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e || !input_ids || !out || !workspace || !st) return fail(LOCO_E_INVALID, "loco_forward_text: null argument");
     if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward_text: call loco_finalize_weights first");
     if (!e->text_embed || !e->text_alpha || !e->text_pe)
         return fail(LOCO_E_STATE, "loco_forward_text: this encoder was loaded without the text prenet weights");
@@ -1369,8 +1370,8 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
     if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(LOCO_E_INVALID, "loco_forward_text: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     Call c;
-    c.precision = e->precision;
-    c.st = e->own;
+    c.precision = precision;
+    c.st = st;
     c.range_dev = reinterpret_cast<float*>(workspace);
     char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
@@ -1394,6 +1395,28 @@ int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* 
     const int rc = c.precision >= 1 ? forward_f16x3(e, c, p, nullptr, out, hidden_states, bufs, s, true)
                                     : forward_f32(e, p, nullptr, out, hidden_states, bufs, s, true);
     return rc ? rc : range_end(c, s);
+}
+}  // namespace
+
+int loco_forward_text(loco_encoder* e, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T, float* out,
+                      int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!e) return fail(LOCO_E_INVALID, "loco_forward_text: null argument");
+    return forward_text_impl(e, e->precision, e->own, input_ids, attention_mask, B, T, out, out_frames, hidden_states, workspace, workspace_bytes, stream);
+}
+
+int loco_forward_text_async(loco_encoder* e, int precision, const int32_t* input_ids, const int32_t* attention_mask, int32_t B, int32_t T,
+                            float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes,
+                            void* stream, void* status) {
+    if (!e || !status) return fail(LOCO_E_INVALID, "loco_forward_text_async: null argument");
+    if (precision != -1 && !loco_precision_name(precision))
+        return fail(LOCO_E_INVALID, "loco_forward_text_async: precision must be -1 (the handle's mode) or one of " LOCO_PRECISION_MODES);
+    if (reinterpret_cast<uintptr_t>(status) & 7) return fail(LOCO_E_INVALID, "loco_forward_text_async: the status block must be 8-byte aligned");
+    StatusBlock* st = reinterpret_cast<StatusBlock*>(status);
+    st->magic = 0;
+    const int rc = forward_text_impl(e, precision < 0 ? e->precision : precision, st, input_ids, attention_mask, B, T, out, out_frames, hidden_states,
+                                     workspace, workspace_bytes, stream);
+    if (rc) st->magic = 0;
+    return rc;
 }
 
 // ---- profiling -----------------------------------------------------------------------------------------

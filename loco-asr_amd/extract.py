@@ -140,15 +140,30 @@ def extract_text(args, items, classes, encode_labels, device, world, rank):
         except Exception as e:  # no hub access / no local files: say what is needed instead of a stack trace
             raise SystemExit(f"-m text needs the SpeechT5 tokenizer files (--tokenizer DIR with spm_char.model): {e}")
         tokenize = lambda idx: [np.asarray(tok(items[i][1])["input_ids"], dtype=np.int64) for i in idx]
+    from collections import deque
+    enc = model.speecht5.encoder
+    inflight = args.inflight if args.inflight > 0 else 4
+    if inflight > 1:
+        enc.set_inflight(inflight)  # batches of transcripts are tiny (<= 2 x ~100 tokens): several in flight, results untouched
+    tickets = deque()
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
+        def finish():
+            i0, t0 = tickets.popleft()
+            emb = (t0.result() if hasattr(t0, "result") else t0).last_hidden_state
+            sink.submit([items[i][0] for i in i0], emb, encode_labels([items[i][4] for i in i0]))
+
         for idx in dp.shard_batches(len(items), args.batch_size, world, rank):  # the reference's batches, dealt whole
             seqs = tokenize(idx)
             T = max(len(q) for q in seqs)
             ids = np.full((len(seqs), T), 1, dtype=np.int64)  # padding="longest" with pad_token_id = 1
             for r, q in enumerate(seqs):
                 ids[r, :len(q)] = q
-            emb = model.speecht5.encoder(torch.from_numpy(ids).to(device)).last_hidden_state
-            sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
+            dev_ids = torch.from_numpy(ids).to(device)
+            tickets.append((idx, enc.forward_async(dev_ids) if inflight > 1 else enc(dev_ids)))
+            while len(tickets) >= inflight:
+                finish()
+        while tickets:
+            finish()
     print("Done!")
 
 

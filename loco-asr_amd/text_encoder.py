@@ -80,6 +80,10 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         self._taps = None
         self.streams = 1
         self.last_frames = None
+        self.range_policy = "fp32"
+        self.last_range_fallback = False
+        self._slots = []       # forwards in flight (forward_async), as in the speech encoder
+        self._next_slot = 0
         self.eval()
 
     def _sync_weights(self, device: torch.device, min_sin_rows: int = 0):
@@ -106,20 +110,9 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         self._ensure_handle(self._device())
         return int(self._lib.loco_text_workspace_bytes(self._handle, batch, tokens))
 
-    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
-                return_dict: Optional[bool] = None, **kwargs):
-        if self.training:
-            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
-        if output_attentions:
-            raise NotImplementedError("output_attentions=True: the flash-style attention kernel never forms the [T,T] weights")
-        ids = input_values
+    def _check_ids(self, ids, attention_mask):
         if ids.dim() != 2 or ids.dtype.is_floating_point or ids.dtype == torch.bool:
             raise ValueError(f"input_values must be integer token ids [batch, tokens], got {ids.dtype} {tuple(ids.shape)}")
-        device = ids.device
-        self._ensure_handle(device)
-        if self._device() != device:
-            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
         B, T = ids.shape
         if T < 1 or B < 1:
             raise ValueError("empty batch")
@@ -128,14 +121,77 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         lo, hi = int(ids.min()), int(ids.max())
         if lo < 0 or hi >= self.vocab_size:
             raise IndexError(f"token id out of range [0, {self.vocab_size}): min {lo}, max {hi}")  # nn.Embedding raises IndexError too
-        ids32 = ids.to(torch.int32).contiguous()
         m = None
         if attention_mask is not None:
             if attention_mask.shape != ids.shape:
                 raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(ids.shape)}")
-            m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+            m = attention_mask.to(device=ids.device, dtype=torch.int32).contiguous()
             if T > 1 and not bool((m[:, 1:] <= m[:, :-1]).all()):
                 raise NotImplementedError("attention_mask must be right padding (ones then zeros), as the tokenizer produces it")
+        return ids.to(torch.int32).contiguous(), m
+
+    # -- several batches of transcripts in flight (the reference's text loop is batch_size = 2 as well, …base…py:67-68,79-93) --------
+    def _enqueue(self, slot, ids32, m, out, frames, precision):
+        B, T = ids32.shape
+        need = int(self._lib.loco_text_workspace_bytes(self._handle, B, T))
+        if slot.workspace is None or slot.workspace.numel() < need:
+            slot.workspace = None
+            slot.workspace = torch.empty(need, dtype=torch.uint8, device=ids32.device)
+        _lib.check(self._lib.loco_forward_text_async(
+            self._handle, self.PRECISIONS[precision], C.c_void_p(ids32.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None, B, T,
+            C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()), slot.workspace.numel(),
+            C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_text_async")
+
+    @torch.no_grad()
+    def forward_async(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, **kwargs):
+        """Enqueue one text forward on the next slot; ``ticket.result()`` is the BaseModelOutput (see the speech encoder's forward_async)."""
+        from .encoder import ForwardTicket
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        device = input_values.device
+        self._ensure_handle(device)
+        if self._device() != device:
+            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
+        if self._weights_dirty:
+            self.drain()
+        if not self._slots:
+            self.set_inflight(2)
+        ids32, m = self._check_ids(input_values, attention_mask)
+        B, T = ids32.shape
+        slot = self._slots[self._next_slot]
+        self._next_slot = (self._next_slot + 1) % len(self._slots)
+        if slot.ticket is not None:
+            slot.ticket.result()
+        with torch.cuda.device(device):
+            self._sync_weights(device)
+            cur = torch.cuda.current_stream(device)
+            slot.stream.wait_stream(cur)
+            with torch.cuda.stream(slot.stream):
+                out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+                frames = torch.empty((B,), dtype=torch.int32, device=device)
+                ids32.record_stream(slot.stream)
+                if m is not None:
+                    m.record_stream(slot.stream)
+                ticket = ForwardTicket(self, slot, ids32, m, out, frames, self.precision)
+                self._enqueue(slot, ids32, m, out, frames, self.precision)
+                ticket._done.record(slot.stream)
+        slot.ticket = ticket
+        return ticket
+
+    def forward(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                output_attentions: Optional[bool] = None, output_hidden_states: Optional[bool] = None,
+                return_dict: Optional[bool] = None, **kwargs):
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        if output_attentions:
+            raise NotImplementedError("output_attentions=True: the flash-style attention kernel never forms the [T,T] weights")
+        ids = input_values
+        device = ids.device
+        self._ensure_handle(device)
+        if self._device() != device:
+            raise RuntimeError(f"module parameters are on {self._device()} but input_values on {device}")
+        ids32, m = self._check_ids(ids, attention_mask)
+        B, T = ids32.shape
         with torch.cuda.device(device):
             self._sync_weights(device)
             _lib.check(self._lib.loco_set_precision(self._handle, self.PRECISIONS[self.precision]), "set_precision")
@@ -161,7 +217,7 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
             launch()
             # numeric range of precision "f16x3" (include/loco_asr.h): same policy as the speech encoder's
             self.last_range_fallback = False
-            policy = getattr(self, "range_policy", "fp32")
+            policy = self.range_policy
             if policy != "off" and self.precision != "f32":
                 torch.cuda.current_stream(device).synchronize()
                 rc = self._lib.loco_forward_status(self._handle, None, 0)

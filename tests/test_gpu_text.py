@@ -103,3 +103,37 @@ def test_error_contract():
     ids = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
     rc = lib().loco_forward_text(sm.speecht5.encoder._handle, ptr(ids), None, 1, 4, ptr(out), None, None, ptr(ws), ws.numel(), stream())
     assert rc != 0 and b"text prenet" in lib().loco_last_error()
+
+
+def test_text_forwards_in_flight_equal_one_at_a_time_bitwise(tmp_path):
+    """The text branch of the reference's loop is batch_size = 2 as well (…base…py:67-68, 79-93): loco_forward_text_async /
+    forward_async keep several batches of transcripts in flight; results equal the synchronous forwards bit for bit, with and without a
+    padding mask, and the CLI writes byte-identical pickles at --inflight 1 and 4."""
+    import importlib
+    import os
+    la = importlib.import_module("loco-asr_amd")
+    sd = la.synth.encoder_state_dict(0, layers=2)
+    _, enc_sd = la.synth.split_state_dict(sd)
+    tpre = {k[len("text_prenet."):]: torch.from_numpy(np.asarray(v)) for k, v in la.synth.text_prenet_state_dict(0).items()}
+    model = la.SpeechT5ForTextToSpeechMI355X.from_state_dicts(tpre, {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=2).cuda()
+    enc = model.speecht5.encoder
+    batches = []
+    for i, (n, lens) in enumerate(((57, [57, 31]), (20, [20, 20]), (90, [44, 90]), (9, [9, 3]), (33, [33, 30]))):
+        ids, mask = la.synth.token_ids(2, n, seed=20 + i, lengths=lens)
+        batches.append((torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda() if i % 2 else None))
+    ref = [enc(x, attention_mask=m).last_hidden_state.clone() for x, m in batches]
+    for k in (2, 4):
+        enc.set_inflight(k)
+        tickets = [enc.forward_async(x, attention_mask=m) for x, m in batches]
+        for t, r in zip(tickets, ref):
+            assert torch.equal(t.result().last_hidden_state, r) and not t.used_fp32
+    extract = importlib.import_module("loco-asr_amd.extract")
+    folders = {}
+    for k in (1, 4):
+        out = str(tmp_path / f"k{k}")
+        extract.main(["-m", "text", "-s", "devel", "--synthetic", "9", "--random-init", "--out", out, "--inflight", str(k)])
+        folders[k] = os.path.join(out, "devel", "text")
+    names = sorted(os.listdir(folders[1]))
+    assert len(names) == 9 and names == sorted(os.listdir(folders[4]))
+    for n in names:
+        assert open(os.path.join(folders[1], n), "rb").read() == open(os.path.join(folders[4], n), "rb").read(), n
