@@ -302,7 +302,9 @@ def main(argv=None):
         idx = my_batches[rnd] if rnd < len(my_batches) else []
         if not idx:
             return idx, None
-        clips = [fetch(i) for i in idx]
+        # a reference batch is two clips: decoded one after the other, the parallelism is across batches; a throughput batch
+        # (--batch-size 32: 32 files of 30 s) is decoded by its own pool, or the GPU waits for one thread to read 30 MB of audio
+        clips = list(clip_pool.map(fetch, idx)) if clip_pool is not None and len(idx) >= 8 else [fetch(i) for i in idx]
         if any(torch.is_tensor(c) for c in clips):  # some files were resampled on the device: the whole batch is padded there
             clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
         feats = processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
@@ -318,6 +320,7 @@ def main(argv=None):
     # the window cache of one decoded recording is not thread-safe: windows are prepared by ONE thread, in order
     n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
     pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None
+    clip_pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 1 and args.batch_size >= 8 and args.window_seconds <= 0 else None
     ahead = max(2, 2 * inflight, n_loaders)  # batches being prepared while others are on the GPU
     pending = [pool.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if pool else []
     encoder = model.speecht5.encoder
@@ -421,8 +424,9 @@ def main(argv=None):
     if args.gather and collective:
         import torch.distributed as dist
         print(f"Embedding gathers issued: {gathers} (backend {dist.get_backend()}, world size {world})")
-    if pool is not None:
-        pool.shutdown()
+    for ex in (pool, clip_pool):
+        if ex is not None:
+            ex.shutdown()
     print("Done!")
     if collective:
         import torch.distributed as dist
