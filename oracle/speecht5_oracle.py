@@ -309,23 +309,29 @@ def encoder_layer_rows(x, rows, frames, sd, lp, pe_k, dtype=torch.float64):
 
 
 @torch.no_grad()
-def feature_encoder_window(x, sd, frame_lo, frame_hi, prefix="prenet.", dtype=torch.float64):
+def feature_encoder_window(x, sd, frame_lo, frame_hi, prefix="prenet.", dtype=torch.float64, stats_cache=None):
     """Frames [frame_lo, frame_hi) of the conv stack (HF:484-494) for ONE clip x [L]: GroupNorm statistics over the
-    whole clip (conv0 is cheap: 1 GFLOP per 30 s), layers 1-6 only on the window's receptive field."""
+    whole clip (conv0 is cheap: 1 GFLOP per 30 s), layers 1-6 only on the window's receptive field.  stats_cache: a dict the
+    caller keeps per clip, so that several windows of one hour-long clip pay for the whole-clip statistics once."""
     x = torch.as_tensor(x).to(dtype)[None, None]
     w0 = _t(sd, prefix + "feature_encoder.conv_layers.0.conv.weight", dtype)
-    # statistics in chunks to bound memory
-    n0 = (x.shape[-1] - 10) // 5 + 1
-    s1 = torch.zeros(512, dtype=torch.float64)
-    s2 = torch.zeros(512, dtype=torch.float64)
-    step = 200000
-    for t0 in range(0, n0, step):
-        t1 = min(n0, t0 + step)
-        y = F.conv1d(x[..., 5 * t0:5 * (t1 - 1) + 10], w0, stride=5)[0].double()
-        s1 += y.sum(1)
-        s2 += (y * y).sum(1)
-    mean = (s1 / n0)
-    var = s2 / n0 - mean * mean
+    if stats_cache is not None and "mean" in stats_cache:
+        mean, var = stats_cache["mean"], stats_cache["var"]
+    else:
+        # statistics in chunks to bound memory
+        n0 = (x.shape[-1] - 10) // 5 + 1
+        s1 = torch.zeros(512, dtype=torch.float64)
+        s2 = torch.zeros(512, dtype=torch.float64)
+        step = 200000
+        for t0 in range(0, n0, step):
+            t1 = min(n0, t0 + step)
+            y = F.conv1d(x[..., 5 * t0:5 * (t1 - 1) + 10], w0, stride=5)[0].double()
+            s1 += y.sum(1)
+            s2 += (y * y).sum(1)
+        mean = (s1 / n0)
+        var = s2 / n0 - mean * mean
+        if stats_cache is not None:
+            stats_cache["mean"], stats_cache["var"] = mean, var
     # receptive field of frames [lo, hi) back through layers 6..1
     lo, hi = frame_lo, frame_hi - 1
     for k, s in reversed(list(zip(CONV_KERNEL[1:], CONV_STRIDE[1:]))):
