@@ -36,6 +36,11 @@ constexpr int AX_STG = 2 * AX_PL;        // hi + lo plane
 typedef __attribute__((address_space(1))) const void* ax_gptr_t;
 typedef __attribute__((address_space(3))) void* ax_lptr_t;
 
+// LOCO_ATTN_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = every table block multiplies pe_k block 0
+// (its fragments stay in the L1: what do the 80 KiB of pe_k planes per wave cost?), 2 = the table is not stored.
+#ifndef LOCO_ATTN_HACK
+#define LOCO_ATTN_HACK 0
+#endif
 #define AX_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define AX_PIN() __builtin_amdgcn_sched_barrier(0)
 
@@ -302,55 +307,83 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     // ---- prologue: K(0), V(0), K(1) in flight; S(0) = K(0) Q^T and its bookkeeping
 #pragma unroll
     for (int pc = 0; pc < 8; ++pc) AX_DMA_PIECE(pc, 0, 0, 0, 0)
-    {
-        const int t1 = ntiles > 1 ? 1 : 0;
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) AX_DMA_PIECE(pc, t1, 0, 1, 0)
-    }
     float c_past, c_future;  // Qp[i][319] (i - j >= 159) and Qp[i][0] (i - j <= -160): the bias of every key beyond the band
     if (TABLE) {
         // Qp^T block blk = pe_k[32 blk .. 32 blk + 31] Q^T: A = pe_k rows (fragment of lane (r, h) at k-step ks: pe_k[32 blk + r][16 ks + 8 h ..
-        // + 7], straight from global memory -- 80 KiB of planes that every workgroup reads: L2 / L1 resident), B = the Q fragments.
-        // acc[e] = Qp[iq][32 blk + (e & 3) + 8 (e >> 2) + 4 h]: four consecutive table entries per e >> 2 -> one 16-byte store.
-        // The weight planes carry pe_k * 2^k (loco_api.hip, make_split): pe_scale = 2^-k restores it, exactly.
+        // + 7]), B = the Q fragments.  acc[e] = Qp[iq][32 blk + (e & 3) + 8 (e >> 2) + 4 h]: four consecutive table entries per e >> 2 ->
+        // one 16-byte store.  The weight planes carry pe_k * 2^k (loco_api.hip, make_split): pe_scale = 2^-k restores it, exactly.
+        //
+        // pe_k reaches the matrix pipe THROUGH LDS, once per workgroup: 64 rows (two blocks, hi + lo planes = 16 KiB) have exactly the
+        // shape of a K tile, so a chunk is DMA'd like one -- same swizzle, same fragment reads -- into the two ring slots the first
+        // iteration does not need yet (K slot 1, V^T slot 1).  Loaded per wave straight from global memory (the first form of this
+        // prologue) every wave pulled the whole 80 KiB through the L2: 1.5 GB per launch at 30 s x 32 beside 3.5 GB of K / V^T, and
+        // 21 000 of a workgroup's 173 000 cycles (tools/attn_stamps.py with the timing-only build LOCO_ATTN_HACK=1).  Three rounds:
+        // blocks 0-3, 4-7, 8-9; a round's accumulators stay in registers until the NEXT chunks' DMAs have been issued, so that the
+        // waits see the table stores and the DMAs together (vmcnt counts both; they may complete out of order, hence vmcnt(0)).
         float cf = 0.f, cp = 0.f;
-        // pe_k fragments of block blk + 1 are fetched while block blk multiplies (two register sets, the loop fully unrolled)
-        h8 fh[2][4], fl[2][4];
-        const long po0 = (long)r * kHeadDim + 8 * h;
+        unsigned pev[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            fh[0][ks] = *reinterpret_cast<const h8*>(pe_hi + po0 + 16 * ks);
-            fl[0][ks] = *reinterpret_cast<const h8*>(pe_lo + po0 + 16 * ks);
+        for (int i = 0; i < 2; ++i) {
+            const int swz = (((2 * wave + i) & 3) << 1) | ((drow >> 1) & 1);
+            pev[i] = (unsigned)(8 * (2 * wave + i) + drow) * (2u * kHeadDim) + 16u * (unsigned)(dpos ^ swz);
         }
+#define AX_PE_DMA(c_, slot_)                                                                                                       \
+    _Pragma("unroll") for (int pc_ = 0; pc_ < 4; ++pc_) {                                                                          \
+        const int i_ = (pc_ >> 1) & 1, pl_ = pc_ & 1;                                                                              \
+        const unsigned d_ = lds0 + 2u * (unsigned)((slot_) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * kHeadDim);               \
+        AX_DMA16(reinterpret_cast<const char*>(pl_ ? pe_lo : pe_hi) + (long)(c_) * (AX_BK * kHeadDim * 2), pev[i_], d_);           \
+    }
+        AX_PE_DMA(0, 1)
+        AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 1, 3)
 #pragma unroll
-        for (int blk = 0; blk < kRelN / 32; ++blk) {
-            if (blk + 1 < kRelN / 32) {
-                const long po = po0 + (long)(32 * (blk + 1)) * kHeadDim;
+        for (int rd = 0; rd < 3; ++rd) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // this round's chunks have landed (and K(0) / V^T(0), and the previous round's table stores)
+            constexpr int kBlocksPerRound = 4;
+            const int nb = rd < 2 ? kBlocksPerRound : kRelN / 32 - 2 * kBlocksPerRound;
+            f32x16 acc[kBlocksPerRound];
+#pragma unroll
+            for (int bb = 0; bb < kBlocksPerRound; ++bb) {
+                if (bb >= nb) break;
+                const _Float16* pb = lds + ((bb >> 1) ? 3 : 1) * AX_STG;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[bb][e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    fh[(blk + 1) & 1][ks] = *reinterpret_cast<const h8*>(pe_hi + po + 16 * ks);
-                    fl[(blk + 1) & 1][ks] = *reinterpret_cast<const h8*>(pe_lo + po + 16 * ks);
+                    const h8 fh = AX_KF(pb, bb & 1, ks, 0), fl = AX_KF(pb, bb & 1, ks, 1);
+                    acc[bb] = AX_MFMA(fl, qh[ks], acc[bb]);
+                    acc[bb] = AX_MFMA(fh, ql[ks], acc[bb]);
+                    acc[bb] = AX_MFMA(fh, qh[ks], acc[bb]);
                 }
             }
-            f32x16 acc;
+            __syncthreads();  // every wave has read both slots: they may be refilled
+            if (rd == 0) {
+                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 2, 1)
+                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 3, 3)
+            } else if (rd == 1) {
+                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 4, 1)
+            } else {
+                const int t1 = ntiles > 1 ? 1 : 0;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                acc = AX_MFMA(fl[blk & 1][ks], qh[ks], acc);
-                acc = AX_MFMA(fh[blk & 1][ks], ql[ks], acc);
-                acc = AX_MFMA(fh[blk & 1][ks], qh[ks], acc);
+                for (int pc = 0; pc < 4; ++pc) AX_DMA_PIECE(pc, t1, 0, 1, 0)  // K(1): its slot is free now
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] *= pe_scale;
-            if (blk == 0) cf = acc[0];                    // table column 0: lane half 0
-            if (blk == kRelN / 32 - 1) cp = acc[15];      // table column 319 = 288 + 3 + 24 + 4: lane half 1
-            if (iq < T) {
+            for (int bb = 0; bb < kBlocksPerRound; ++bb) {
+                if (bb >= nb) break;
+                const int blk = kBlocksPerRound * rd + bb;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    *reinterpret_cast<float4*>(qprow + 32 * blk + 8 * g4 + 4 * h) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+                for (int e = 0; e < 16; ++e) acc[bb][e] *= pe_scale;
+                if (blk == 0) cf = acc[bb][0];                    // table column 0: lane half 0
+                if (blk == kRelN / 32 - 1) cp = acc[bb][15];      // table column 319 = 288 + 3 + 24 + 4: lane half 1
+                if (iq < T && (LOCO_ATTN_HACK != 2 || T < 0)) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(qprow + 32 * blk + 8 * g4 + 4 * h) =
+                            make_float4(acc[bb][4 * g4], acc[bb][4 * g4 + 1], acc[bb][4 * g4 + 2], acc[bb][4 * g4 + 3]);
+                }
             }
         }
+#undef AX_PE_DMA
         // both lane halves of a query need both constants: one swap each (after it the first register holds the lower half's
         // value in both halves, the second the upper half's -- see the row maximum below for why this is inline asm)
         float cf2 = cf, cp2 = cp;
@@ -359,8 +392,11 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         c_future = cf;  // lower half's
         c_past = cp;    // upper half's
         // the band tiles of THIS wave read these rows back (other lanes of it): the stores must have reached L2 first -- the
-        // vmcnt(0) right below, which also retires the first K / V^T tiles' DMAs that were in flight during all of the above
+        // vmcnt(0) right below, which also retires K(1)'s DMAs
     } else {
+        const int t1 = ntiles > 1 ? 1 : 0;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) AX_DMA_PIECE(pc, t1, 0, 1, 0)
         c_past = qprow[kRelN - 1];
         c_future = qprow[0];
     }
