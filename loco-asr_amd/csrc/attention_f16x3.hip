@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                                                                  const _Float16* __restrict__ pe_hi, const _Float16* __restrict__ pe_lo,
                                                                  float pe_scale) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * AX_STG];  // K ring (2 tiles), V^T ring (2 tiles)
-    __shared__ float bias_stage[4][32 * 17];
+    __shared__ __attribute__((aligned(16))) float bias_stage[4][32 * 17];
 
     // XCD-aware work map: workgroups whose ids are congruent mod 8 share an XCD (and its private L2).  Each XCD is given a
     // contiguous run of (clip, head, query-block) items with the query block fastest, so the query blocks of one
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         // shape of a K tile, so a chunk is DMA'd like one -- same swizzle, same fragment reads -- into the two ring slots the first
         // iteration does not need yet (K slot 1, V^T slot 1).  Loaded per wave straight from global memory (the first form of this
         // prologue) every wave pulled the whole 80 KiB through the L2: 1.5 GB per launch at 30 s x 32 beside 3.5 GB of K / V^T, and
-        // 21 000 of a workgroup's 173 000 cycles (tools/attn_stamps.py with the timing-only build LOCO_ATTN_HACK=1).  Three rounds:
-        // blocks 0-3, 4-7, 8-9; a round's accumulators stay in registers until the NEXT chunks' DMAs have been issued, so that the
-        // waits see the table stores and the DMAs together (vmcnt counts both; they may complete out of order, hence vmcnt(0)).
+        // 21 000 of a workgroup's 173 000 cycles (tools/attn_stamps.py with the timing-only build LOCO_ATTN_HACK=1).  Two rounds of
+        // five blocks; a round's accumulators stay in registers until the NEXT round's DMAs have been issued, so that each wait
+        // sees table stores and DMAs together (vmcnt counts both; they may complete out of order, hence vmcnt(0)).
         float cf = 0.f, cp = 0.f;
         unsigned pev[2];
 #pragma unroll
@@ -327,41 +327,52 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             const int swz = (((2 * wave + i) & 3) << 1) | ((drow >> 1) & 1);
             pev[i] = (unsigned)(8 * (2 * wave + i) + drow) * (2u * kHeadDim) + 16u * (unsigned)(dpos ^ swz);
         }
-#define AX_PE_DMA(c_, slot_)                                                                                                       \
+        // a fifth block per round sits in the per-wave bias scratch (8.5 KiB, idle until the first band tile): 32 rows, wave w moves rows 8 w ..
+        const unsigned bs0 = (unsigned)(unsigned long)(ax_lptr_t)&bias_stage[0][0];
+        const unsigned pev1 = (unsigned)(8 * wave + drow) * (2u * kHeadDim) + 16u * (unsigned)(dpos ^ (((wave & 3) << 1) | ((drow >> 1) & 1)));
+        constexpr int kBsPlane = 32 * kHeadDim;  // halves per plane of the single block
+        // blocks b0_, b0_ + 1 -> ring slot slot_ (pe_k rows 32 b0_ .. + 63: the shape and swizzle of a K tile)
+#define AX_PE_DMA2(b0_, slot_)                                                                                                     \
     _Pragma("unroll") for (int pc_ = 0; pc_ < 4; ++pc_) {                                                                          \
         const int i_ = (pc_ >> 1) & 1, pl_ = pc_ & 1;                                                                              \
         const unsigned d_ = lds0 + 2u * (unsigned)((slot_) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * kHeadDim);               \
-        AX_DMA16(reinterpret_cast<const char*>(pl_ ? pe_lo : pe_hi) + (long)(c_) * (AX_BK * kHeadDim * 2), pev[i_], d_);           \
+        AX_DMA16(reinterpret_cast<const char*>(pl_ ? pe_lo : pe_hi) + (long)(b0_) * (32 * kHeadDim * 2), pev[i_], d_);             \
     }
-        AX_PE_DMA(0, 1)
-        AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 1, 3)
+#define AX_PE_DMA1(b0_)                                                                                                            \
+    _Pragma("unroll") for (int pl_ = 0; pl_ < 2; ++pl_) {                                                                          \
+        const unsigned d_ = bs0 + 2u * (unsigned)(pl_ * kBsPlane + 8 * wave * kHeadDim);                                           \
+        AX_DMA16(reinterpret_cast<const char*>(pl_ ? pe_lo : pe_hi) + (long)(b0_) * (32 * kHeadDim * 2), pev1, d_);                \
+    }
+        constexpr int kBlocksPerRound = kRelN / 64;  // 5
+        static_assert(2 * kBlocksPerRound * 32 == kRelN && sizeof(bias_stage) >= 2 * kBsPlane * sizeof(_Float16), "table rounds");
+#define AX_PE_ROUND_DMA(rd_)                                                                      \
+    AX_PE_DMA2(LOCO_ATTN_HACK == 1 ? 0 : kBlocksPerRound * (rd_), 1)                               \
+    AX_PE_DMA2(LOCO_ATTN_HACK == 1 ? 0 : kBlocksPerRound * (rd_) + 2, 3)                           \
+    AX_PE_DMA1(LOCO_ATTN_HACK == 1 ? 0 : kBlocksPerRound * (rd_) + 4)
+        AX_PE_ROUND_DMA(0)
 #pragma unroll
-        for (int rd = 0; rd < 3; ++rd) {
+        for (int rd = 0; rd < 2; ++rd) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // this round's chunks have landed (and K(0) / V^T(0), and the previous round's table stores)
-            constexpr int kBlocksPerRound = 4;
-            const int nb = rd < 2 ? kBlocksPerRound : kRelN / 32 - 2 * kBlocksPerRound;
+            __syncthreads();  // this round's blocks have landed (and K(0) / V^T(0), and the previous round's table stores)
             f32x16 acc[kBlocksPerRound];
 #pragma unroll
             for (int bb = 0; bb < kBlocksPerRound; ++bb) {
-                if (bb >= nb) break;
-                const _Float16* pb = lds + ((bb >> 1) ? 3 : 1) * AX_STG;
+                const _Float16* pb = bb == 4 ? reinterpret_cast<const _Float16*>(&bias_stage[0][0]) : lds + ((bb >> 1) ? 3 : 1) * AX_STG;
+                const int plane = bb == 4 ? kBsPlane : AX_PL;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[bb][e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const h8 fh = AX_KF(pb, bb & 1, ks, 0), fl = AX_KF(pb, bb & 1, ks, 1);
+                    const h8 fh = *reinterpret_cast<const h8*>(pb + (bb & 1) * 32 * kHeadDim + fo[ks]);
+                    const h8 fl = *reinterpret_cast<const h8*>(pb + plane + (bb & 1) * 32 * kHeadDim + fo[ks]);
                     acc[bb] = AX_MFMA(fl, qh[ks], acc[bb]);
                     acc[bb] = AX_MFMA(fh, ql[ks], acc[bb]);
                     acc[bb] = AX_MFMA(fh, qh[ks], acc[bb]);
                 }
             }
-            __syncthreads();  // every wave has read both slots: they may be refilled
+            __syncthreads();  // every wave has read the three buffers: they may be refilled
             if (rd == 0) {
-                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 2, 1)
-                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 3, 3)
-            } else if (rd == 1) {
-                AX_PE_DMA(LOCO_ATTN_HACK == 1 ? 0 : 4, 1)
+                AX_PE_ROUND_DMA(1)
             } else {
                 const int t1 = ntiles > 1 ? 1 : 0;
 #pragma unroll
@@ -369,7 +380,6 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
             }
 #pragma unroll
             for (int bb = 0; bb < kBlocksPerRound; ++bb) {
-                if (bb >= nb) break;
                 const int blk = kBlocksPerRound * rd + bb;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[bb][e] *= pe_scale;
@@ -383,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 }
             }
         }
-#undef AX_PE_DMA
+#undef AX_PE_ROUND_DMA
+#undef AX_PE_DMA2
+#undef AX_PE_DMA1
         // both lane halves of a query need both constants: one swap each (after it the first register holds the lower half's
         // value in both halves, the second the upper half's -- see the row maximum below for why this is inline asm)
         float cf2 = cf, cp2 = cp;
