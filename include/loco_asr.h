@@ -340,20 +340,17 @@ int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, con
                               int32_t M, int32_t N, int32_t K, int32_t epilogue, void* splitk_ws, size_t splitk_bytes,
                               void* stream);
 
-/* split-precision attention core: q, k as fp16 hi/lo planes [B*T,768] (q pre-scaled by 1/8), v TRANSPOSED per head as
- * planes [(b*12+head)*64+d][Tp] with Tp % 64 == 0 and zero padding for t >= T, frame t stored in column
- * loco_op_vt_column(t) (a permutation inside each aligned group of 16 frames: the order the matrix instruction consumes
- * keys in, which is what the fused q|k|v projection writes); qp/frames/ctx as loco_op_attention. */
-int32_t loco_op_vt_column(int32_t t);
-int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi,
-                            const void* vtlo, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
-                            int32_t Tp, void* stream);
+/* split-precision attention core: q, k and v as fp16 hi/lo planes [B*T,768] (q pre-scaled by 1/8) -- the layout the fused q|k|v
+ * projection writes; the kernel transposes its V tiles with the LDS read; qp/frames/ctx as loco_op_attention. */
+int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vhi,
+                            const void* vlo, const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T,
+                            void* stream);
 /* The form loco_forward runs: the relative-position table qp[b, head, i, 0..319] = q_scaled[i] . pe_k^T * pe_scale is computed by the
  * attention kernel itself (each wave for its own 32 queries) from pe_k as fp16 hi/lo planes [320][64] -- no table GEMM in front
  * of it -- into qp_scratch ([B,12,T,320] fp32: written and read back by the launch; holds the table afterwards). */
-int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
+int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vhi, const void* vlo,
                                const void* pe_hi, const void* pe_lo, float pe_scale, float* qp_scratch, const int32_t* frames,
-                               float* ctx, int32_t B, int32_t T, int32_t Tp, void* stream);
+                               float* ctx, int32_t B, int32_t T, void* stream);
 
 /* ---- intent head: the first consumer of the embeddings ("next" row f-1) --------------------------------------
  * IntentClassifier (/root/reference/speech_text/intent_classifier.py:24-49): pooling over time

@@ -78,7 +78,6 @@ SIGNATURES = {
     "loco_op_pos_conv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_op_split_f16": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "loco_op_vt_column": (C.c_int32, [_i32]),
     "loco_gemm_splitk_bytes": (_sz, []),
     "loco_debug_reload_gemm_knobs": (None, []),
     "loco_op_gemm_f16x3_splitk": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32,
@@ -87,8 +86,8 @@ SIGNATURES = {
                                      _i32, _i32, _i64, _i64, _i64, _i64, _vp]),
     "loco_op_permute_conv_k": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "loco_op_conv_gemm_f16x3": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _vp]),
-    "loco_op_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "loco_op_attention_f16x3_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "loco_op_attention_f16x3": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "loco_op_attention_f16x3_pe": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i32, _i32, _vp]),
     "loco_head_last_error": (C.c_char_p, []),
     "loco_head_create": (_vp, [C.c_int]),
     "loco_head_destroy": (None, [_vp]),

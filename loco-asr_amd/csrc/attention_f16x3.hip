@@ -4,19 +4,22 @@
 // with both matrix products issued as three v_mfma_f32_32x32x16_f16 per fp32-class product:
 //
 //   S^T  += K_lo Q_hi^T + K_hi Q_lo^T + K_hi Q_hi^T          (q, k arrive as fp16 hi/lo planes from the QKV GEMM epilogue)
-//   O^T  += V_lo^T P_hi + V_hi^T P_lo + V_hi^T P_hi           (P = exp2(..) is split in registers, V^T planes come
-//                                                              TRANSPOSED [head*64+d][t] from the same epilogue)
+//   O^T  += V_lo^T P_hi + V_hi^T P_lo + V_hi^T P_hi           (P = exp2(..) is split in registers; V arrives ROW-major
+//                                                              like q and k and is transposed by the LDS read)
 //
 // 48 MFMAs x 32 cycles per 64-key tile and wave instead of 128 x 64 cycles: 5.3x fewer matrix-pipe cycles; softmax
 // statistics, the running (m, l) and the O accumulators stay fp32.
 //
 // P as the next MFMA's B operand without touching LDS: the C/D fragment of S^T holds, in lane-half h, register 8s+j,
 // key 16s + 8(j>>2) + 4h + (j&3) of a 32-key sub-tile; the 32x32x16 B operand wants k = 8h + j from that lane half, so
-// registers 8s..8s+7 ARE k-step s up to a permutation of k.  The same permutation is baked into the V^T planes (frame t
-// sits in column vt_col(t), loco_kernels.h), so the matching A fragment is one contiguous 16-byte piece.
+// registers 8s..8s+7 ARE k-step s up to a permutation of k: lane half h holds keys 16s + 4h + {0..3} and 16s + 8 + 4h + {0..3}.
+// The matching A fragment -- V[those 8 keys][d = the lane's row] -- is gathered from the row-major V tile by two
+// ds_read_b64_tr_b16 (a 4-key x 16-d block per 16 lanes, delivered column-major: element q of lane i = key q, d = i), so V needs
+// no transposed copy in memory.  (Rounds 1-2 had the QKV epilogue write V^T planes with the permutation baked in: 2-byte stores a row
+// pitch apart, 0.76 ms per step at 30 s x 32, a memset of the pad columns per forward and a reduction kernel of its own.)
 //
-// LDS: two-deep rings of K and V^T tiles (hi + lo planes, 64 rows x 128 bytes, unpadded: filled by LDS-DMA, 16-byte pieces
-// XOR-swizzled on the source address so that ds_read_b128 is conflict-free) = 64 KiB + the per-wave bias transpose
+// LDS: two-deep rings of K and V tiles (hi + lo planes, 64 keys x 128 bytes, unpadded: filled by LDS-DMA, 16-byte pieces
+// XOR-swizzled on the source address so that ds_read_b128 (K) and ds_read_b64_tr_b16 (V) are conflict-free) = 64 KiB + the per-wave bias transpose
 // scratch = 72.5 KiB, two workgroups per CU.  The loop is software-pipelined INSIDE each wave (QK of tile t+1 against the
 // softmax of tile t, see the main loop): the chip is power-limited here, so what that buys is fewer stalls per joule, not
 // a higher matrix-pipe duty cycle at the nominal clock.
@@ -97,6 +100,13 @@ __device__ float* g_attn_dbg = nullptr;  // [workgroup][thread][tile < 8][8 floa
 #define AX_DBG(tile_, code_, S0_, S1_) {}
 #endif
 
+// two transposed 64-bit LDS reads (4 keys each) -> the 8-half A fragment of one 16-key step
+typedef __fp16 ax_tr4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h8 ax_join_tr(ax_tr4_t a, ax_tr4_t b) {
+    const h4 x = __builtin_bit_cast(h4, a), y = __builtin_bit_cast(h4, b);
+    return h8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+}
+
 // TABLE: the relative-position table Qp[b, head, i, 0..319] = q_scaled[i] . pe_k^T (HF modeling:432-441, 939-945) is computed HERE,
 // by the wave that owns query i, instead of by a GEMM launch in front of this kernel: ten 32x32 blocks of Qp^T = pe_k Q^T on the
 // Q fragments already in registers (120 MFMAs per wave: what the table GEMM spent), written to the same [B,12,T,320] buffer and
@@ -106,10 +116,10 @@ __device__ float* g_attn_dbg = nullptr;  // [workgroup][thread][tile < 8][8 floa
 template <bool OUT_SPLIT, bool TABLE>
 __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16* __restrict__ qhi, const _Float16* __restrict__ qlo,
                                                                  const _Float16* __restrict__ khi, const _Float16* __restrict__ klo,
-                                                                 const _Float16* __restrict__ vthi, const _Float16* __restrict__ vtlo,
+                                                                 const _Float16* __restrict__ vhi, const _Float16* __restrict__ vlo,
                                                                  float* qp, const int32_t* __restrict__ frames,
                                                                  _Float16* __restrict__ ctx_hi, _Float16* __restrict__ ctx_lo,
-                                                                 float* __restrict__ ctx, int T, int Tp, int nqb,
+                                                                 float* __restrict__ ctx, int T, int nqb,
                                                                  const _Float16* __restrict__ pe_hi, const _Float16* __restrict__ pe_lo,
                                                                  float pe_scale) {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * AX_STG];  // K ring (2 tiles), V^T ring (2 tiles)
@@ -166,33 +176,33 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     // branching: the surplus DMAs of the last two iterations re-fetch it into a slot whose tile has been consumed, and the
     // vmcnt(0) that ends every iteration retires them.
     const unsigned lds0 = (unsigned)(unsigned long)(ax_lptr_t)lds;
-    unsigned kvc[2], vvo[2];  // K: column part of the lane offset (the row part depends on the clamp at T); V^T: the whole offset
+    // column part of the lane offset (the row part depends on the clamp at T).  K pieces are swizzled for its ds_read_b128 fragments
+    // (above); V pieces by {row bit 1} << 2: a transposed read takes, per 32 lanes, 4 consecutive keys x one 64-byte half of their
+    // rows -- keys q and q + 2 fall on the same bank half (128-byte rows), so the swizzle sends them to different 64-byte halves.
+    unsigned kvc[2], vvc;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int swz = (((2 * wave + i) & 3) << 1) | ((drow >> 1) & 1);
         kvc[i] = 2u * (unsigned)(head * kHeadDim + 8 * (dpos ^ swz));
-        vvo[i] = 2u * (unsigned)((8 * (2 * wave + i) + drow) * Tp + 8 * (dpos ^ swz));
     }
+    vvc = 2u * (unsigned)(head * kHeadDim + 8 * (dpos ^ (((drow >> 1) & 1) << 2)));
     const char* const kbase_h = reinterpret_cast<const char*>(khi + (long)b * T * kHidden);
     const char* const kbase_l = reinterpret_cast<const char*>(klo + (long)b * T * kHidden);
-    const char* const vbase_h = reinterpret_cast<const char*>(vthi + ((long)b * kHidden + head * kHeadDim) * Tp);
-    const char* const vbase_l = reinterpret_cast<const char*>(vtlo + ((long)b * kHidden + head * kHeadDim) * Tp);
+    const char* const vbase_h = reinterpret_cast<const char*>(vhi + (long)b * T * kHidden);
+    const char* const vbase_l = reinterpret_cast<const char*>(vlo + (long)b * T * kHidden);
 #define AX_DMA16(base_, voff_, ldsb_) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 #define AX_DMA_PIECE(pc_, tk_, tv_, kslot_, vslot_)                                                                          \
     {                                                                                                                        \
         const int i_ = ((pc_) >> 1) & 1, pl_ = (pc_) & 1;                                                                    \
-        if ((pc_) < 4) {                                                                                                     \
-            const int rmax_ = T - 1 - (tk_) * AX_BK; /* rows of the tile past the last key read key T-1 (masked later) */    \
-            int row_ = 8 * (2 * wave + i_) + drow;                                                                           \
-            row_ = row_ < rmax_ ? row_ : rmax_;                                                                              \
-            const unsigned vo_ = (unsigned)row_ * (2u * kHidden) + kvc[i_];                                                  \
-            const unsigned d_ = lds0 + 2u * (unsigned)((kslot_) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * kHeadDim);    \
-            AX_DMA16((pl_ ? kbase_l : kbase_h) + (long)(tk_) * (AX_BK * kHidden * 2), vo_, d_);                              \
-        } else {                                                                                                             \
-            const unsigned d_ = lds0 + 2u * (unsigned)((2 + (vslot_)) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * AX_BK); \
-            AX_DMA16((pl_ ? vbase_l : vbase_h) + (long)(tv_) * (AX_BK * 2), vvo[i_], d_);                                    \
-        }                                                                                                                    \
+        const bool isk_ = (pc_) < 4;                                                                                         \
+        const int tt_ = isk_ ? (tk_) : (tv_);                                                                                \
+        const int rmax_ = T - 1 - tt_ * AX_BK; /* rows of the tile past the last key read key T-1 (masked later) */          \
+        int row_ = 8 * (2 * wave + i_) + drow;                                                                               \
+        row_ = row_ < rmax_ ? row_ : rmax_;                                                                                  \
+        const unsigned vo_ = (unsigned)row_ * (2u * kHidden) + (isk_ ? kvc[i_] : vvc);                                       \
+        const unsigned d_ = lds0 + 2u * (unsigned)((isk_ ? (kslot_) : 2 + (vslot_)) * AX_STG + pl_ * AX_PL + 8 * (2 * wave + i_) * kHeadDim); \
+        AX_DMA16((isk_ ? (pl_ ? kbase_l : kbase_h) : (pl_ ? vbase_l : vbase_h)) + (long)tt_ * (AX_BK * kHidden * 2), vo_, d_); \
     }
 
     // fragment addresses (halves, within a tile): row 32 x + r, piece (2 y + h) ^ swz(r); x = key sub-tile (K) or d half
@@ -205,7 +215,22 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         for (int y = 0; y < 4; ++y) fo[y] = r * kHeadDim + 8 * ((2 * y + h) ^ swz);
     }
 #define AX_KF(kb_, st_, ks_, pl_) (*reinterpret_cast<const h8*>((kb_) + (pl_) * AX_PL + (st_) * 32 * kHeadDim + fo[ks_]))
-#define AX_VF(vb_, dt_, c_, pl_) (*reinterpret_cast<const h8*>((vb_) + (pl_) * AX_PL + (dt_) * 32 * AX_BK + fo[c_]))
+    // V^T fragment of the 16-key step c_ (keys 16 c_ .. + 15 of the tile), d half dt_: lane (group G = lane / 16: h = G / 2, column half
+    // g = G % 2; q = (lane / 4) % 4, p = lane % 4) supplies the address of key 16 c_ + 4 h + 8 u + q, d = 32 dt_ + 16 g + 4 p .. + 3 and
+    // receives, for u = 0, 1, keys 16 c_ + 4 h + 8 u + {0..3} at d = 32 dt_ + (lane % 32): exactly elements 4 u .. 4 u + 3 of the A operand
+    // whose k = 8 h + j pairs with P's register order.  vfo[dt_] holds the lane part (the swizzle bit follows q, so dt_ cannot be an immediate).
+    int vfo[2];
+    {
+        const int q = (lane >> 2) & 3, pp = lane & 3, g = (lane >> 4) & 1;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            vfo[dt] = (4 * h + q) * kHeadDim + 8 * ((4 * (dt ^ ((q >> 1) & 1))) + 2 * g + (pp >> 1)) + 4 * (pp & 1);
+    }
+    typedef __fp16 ax_tr4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    typedef __attribute__((address_space(3))) ax_tr4* ax_tr4_lptr;
+#define AX_VTR(vb_, dt_, c_, u_, pl_) \
+    __builtin_amdgcn_ds_read_tr16_b64_v4f16((ax_tr4_lptr)((vb_) + (pl_) * AX_PL + (16 * (c_) + 8 * (u_)) * kHeadDim + vfo[dt_]))
+#define AX_VF(vb_, dt_, c_, pl_) ax_join_tr(AX_VTR(vb_, dt_, c_, 0, pl_), AX_VTR(vb_, dt_, c_, 1, pl_))
 
     f32x16 o0, o1;
 #pragma unroll
@@ -559,6 +584,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
 #undef AX_DMA16
 #undef AX_KF
 #undef AX_VF
+#undef AX_VTR
 
 #ifdef LOCO_ATTN_STAMPS
     if (g_attn_stamps && tid == 0) {
@@ -599,10 +625,10 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
 }
 
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
-                                  const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
-                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s,
+                                  const _Float16* vhi, const _Float16* vlo, const float* qp, const int32_t* frames,
+                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, hipStream_t s,
                                   const _Float16* pe_hi, const _Float16* pe_lo, float pe_scale) {
-    if (B <= 0 || T <= 0 || B > 65535 || Tp < T || (Tp % AX_BK) != 0) return hipErrorInvalidValue;
+    if (B <= 0 || T <= 0 || B > 65535) return hipErrorInvalidValue;
     const int nqb = (T + AX_BQ - 1) / AX_BQ;
     const long nblk = (long)nqb * kHeads * B;
     if (nblk > 0x7fffffffL) return hipErrorInvalidValue;
@@ -610,8 +636,8 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
     float* qpw = const_cast<float*>(qp);  // written only in the pe_hi != nullptr form (the table is then an output / scratch of this launch)
     if ((pe_hi == nullptr) != (pe_lo == nullptr)) return hipErrorInvalidValue;
 #define AX_LAUNCH(SPLIT_, TABLE_)                                                                                                      \
-    hipLaunchKernelGGL((attention_f16x3_kernel<SPLIT_, TABLE_>), grid, dim3(256), 0, s, qhi, qlo, khi, klo, vthi, vtlo, qpw, frames, ctx_hi, \
-                       ctx_lo, ctx, T, Tp, nqb, pe_hi, pe_lo, pe_scale)
+    hipLaunchKernelGGL((attention_f16x3_kernel<SPLIT_, TABLE_>), grid, dim3(256), 0, s, qhi, qlo, khi, klo, vhi, vlo, qpw, frames, ctx_hi, \
+                       ctx_lo, ctx, T, nqb, pe_hi, pe_lo, pe_scale)
     if (ctx_hi && pe_hi) AX_LAUNCH(true, true);
     else if (ctx_hi) AX_LAUNCH(true, false);
     else if (pe_hi) AX_LAUNCH(false, true);

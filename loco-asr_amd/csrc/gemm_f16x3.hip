@@ -80,16 +80,9 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
         } else if (n < 2 * kHidden) {  // k
             *reinterpret_cast<h4*>(p.Khi + (long)m * kHidden + n - kHidden) = hi;
             *reinterpret_cast<h4*>(p.Klo + (long)m * kHidden + n - kHidden) = lo;
-        } else {  // v, transposed per head: row (b*12 + head)*64 + d, column vt_col(t) (loco_kernels.h)
-            const int b = m / p.T, t = m - b * p.T;
-            const long row = (long)b * kHidden + (n - 2 * kHidden);
-            const int tc = vt_col(t);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (LOCO_GEMM_HACK == 5 && p.M > 0) continue;  // timing-only: what do the 2-byte transposed V stores cost?
-                p.Vthi[(row + e) * p.Tp + tc] = hi[e];
-                p.Vtlo[(row + e) * p.Tp + tc] = lo[e];
-            }
+        } else {  // v: row-major like q and k (attention transposes it with ds_read_b64_tr_b16)
+            *reinterpret_cast<h4*>(p.Vhi + (long)m * kHidden + n - 2 * kHidden) = hi;
+            *reinterpret_cast<h4*>(p.Vlo + (long)m * kHidden + n - 2 * kHidden) = lo;
         }
     } else {
         const long o = coff + (long)m * p.ldc + n;
@@ -105,7 +98,7 @@ template <int EPI, bool OUT_SPLIT>
 __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4 (&v)[4], long coff, int m, int n, float& amax, int z1,
                                                    int z2) {
     constexpr bool wide_epi = EPI == kEpiNone || EPI == kEpiGelu || EPI == kEpiResidual || EPI == kEpiQkvScatter;
-    if (!wide_epi || n + 16 > p.N || (EPI == kEpiQkvScatter && n >= 2 * kHidden)) {
+    if (!wide_epi || n + 16 > p.N) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (n + 4 * j < p.N) split_gemm_store<EPI, OUT_SPLIT>(p, v[j], coff, m, n + 4 * j, amax, z1, z2);
@@ -155,10 +148,10 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
     }
     _Float16 *dh, *dl;
     if (EPI == kEpiQkvScatter) {
-        const bool isq = n < kHidden;
-        const long o = (long)m * kHidden + (isq ? n : n - kHidden);
-        dh = (isq ? p.Chi : p.Khi) + o;
-        dl = (isq ? p.Clo : p.Klo) + o;
+        const int third = n < kHidden ? 0 : (n < 2 * kHidden ? 1 : 2);  // a run of 16 columns never straddles q | k | v (768 = 48 x 16)
+        const long o = (long)m * kHidden + (n - third * kHidden);
+        dh = (third == 0 ? p.Chi : third == 1 ? p.Khi : p.Vhi) + o;
+        dl = (third == 0 ? p.Clo : third == 1 ? p.Klo : p.Vlo) + o;
     } else {
         const long o = coff + (long)m * p.ldc + n;
         dh = p.Chi + o;
@@ -212,7 +205,7 @@ typedef __attribute__((address_space(3))) const h8* lds_h8p;
 // nothing else in this kernel uses it -- gfx9 DS instructions do not -- and tests/test_isa_patterns.py checks that.)
 // LOCO_GEMM_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = no LDS-DMA is issued (what does the
 // L2 -> LDS traffic cost?), 2 = row groups 1 and 3 re-use the A fragments of 0 and 2 (a quarter of the LDS reads gone), 4 = no
-// epilogue stores, 5 = no transposed V stores in the q|k|v scatter, 6 = only waves 0-3 issue LDS-DMA (with tools/gemm_stamps.py).
+// epilogue stores, 6 = only waves 0-3 issue LDS-DMA (with tools/gemm_stamps.py).
 #if LOCO_GEMM_HACK == 1
 #define DMA16(base_, voff_, ldsb_) asm volatile("" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 #elif LOCO_GEMM_HACK == 6  // only waves 0-3 (one per SIMD) issue their DMA pieces: do the four waves of a SIMD collide in DMA issue?
@@ -650,14 +643,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmSplitArgs p, int
     if (OUT_SPLIT || EPI == kEpiQkvScatter) range_commit_block(p.range_slot, amax, seen);  // every thread of the block gets here
 }
 
-// The same reduction for the fused q|k|v projection (kEpiQkvScatter), one 64-row x 64-column tile per workgroup.  The generic
-// kernel above hands a thread four columns of one row, which for the V third means four 2-byte stores into four different rows of
-// the transposed planes, a row pitch apart from its neighbours' -- 125 us for 1 497 rows, twice the GEMM it finishes (3 ms of a
-// 9.8 ms forward of 6 x 10 s run as two half-batches).  Here the V tiles go through an LDS tile and are written with the frame on
-// the lane: one wave instruction stores 64 consecutive frames of one V^T row (128 contiguous bytes, permuted inside aligned groups
-// of 16 by vt_col).
+// The same reduction for the fused q|k|v projection (kEpiQkvScatter), one 64-row x 64-column tile per workgroup: a thread owns four
+// columns of a row, 16 threads complete a 128-byte run of one plane row.  (While V was stored transposed this kernel sent the V tiles
+// through LDS to write them with the frame on the lane; V is row-major now, like q and k.)
 __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p, int ks) {
-    __shared__ float tile[64][65];
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     const int c4 = tid & 15, r0 = tid >> 4;
@@ -665,6 +654,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p,
     const unsigned seen = range_peek(p.range_slot);
     const int n = n0 + 4 * c4;
     const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int third = n0 < kHidden ? 0 : (n0 < 2 * kHidden ? 1 : 2);  // block-uniform: 768 = 12 x 64
+    _Float16* const dh = third == 0 ? p.Chi : third == 1 ? p.Khi : p.Vhi;
+    _Float16* const dl = third == 0 ? p.Clo : third == 1 ? p.Klo : p.Vlo;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int ml = r0 + 16 * rr, m = m0 + ml;
@@ -674,37 +666,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p,
         for (int k = 1; k < ks; ++k) v += *reinterpret_cast<const f32x4*>(part + (long)k * p.M * p.N);
         v = v * p.out_scale + bias;
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-        if (n0 < 2 * kHidden) {  // q or k: plane rows, 8 bytes per thread, 128 contiguous bytes per 16 threads
-            unsigned h0, l0, h1, l1;
-            split_f16_2pairs(v[0], v[1], v[2], v[3], h0, l0, h1, l1);
-            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-            const bool isq = n0 < kHidden;
-            const long o = (long)m * kHidden + (isq ? n : n - kHidden);
-            *reinterpret_cast<u32x2_t*>((isq ? p.Chi : p.Khi) + o) = u32x2_t{h0, h1};
-            *reinterpret_cast<u32x2_t*>((isq ? p.Clo : p.Klo) + o) = u32x2_t{l0, l1};
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tile[ml][4 * c4 + e] = v[e];
-        }
-    }
-    if (n0 >= 2 * kHidden) {  // block-uniform
-        __syncthreads();
-        const int lane = tid & 63, wave = tid >> 6;
-        const int m = m0 + lane;
-        if (m < p.M) {
-            const int b = m / p.T, t = m - b * p.T;
-            const long col = vt_col(t);
-#pragma unroll 4
-            for (int dd = 0; dd < 16; ++dd) {
-                const int d = 16 * wave + dd;
-                const float x = tile[lane][d];
-                const _Float16 hi = (_Float16)x;
-                const _Float16 lo = (_Float16)(x - (float)hi);
-                const long row = (long)b * kHidden + (n0 - 2 * kHidden) + d;
-                p.Vthi[row * p.Tp + col] = hi;
-                p.Vtlo[row * p.Tp + col] = lo;
-            }
-        }
+        unsigned h0, l0, h1, l1;
+        split_f16_2pairs(v[0], v[1], v[2], v[3], h0, l0, h1, l1);
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const long o = (long)m * kHidden + (n - third * kHidden);
+        *reinterpret_cast<u32x2_t*>(dh + o) = u32x2_t{h0, h1};
+        *reinterpret_cast<u32x2_t*>(dl + o) = u32x2_t{l0, l1};
     }
     range_commit_block(p.range_slot, amax, seen);
 }
@@ -800,7 +767,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     const bool split = a.Chi != nullptr;
     if (split ? (a.Clo == nullptr) : (a.C == nullptr)) return hipErrorInvalidValue;
     if (a.epilogue == kEpiQkvScatter &&
-        (!split || !a.Khi || !a.Klo || !a.Vthi || !a.Vtlo || a.N != kQkv || a.T <= 0 || a.Tp < a.T || a.nb1 * a.nb2 != 1))
+        (!split || !a.Khi || !a.Klo || !a.Vhi || !a.Vlo || a.N != kQkv || a.nb1 * a.nb2 != 1))
         return hipErrorInvalidValue;
     if (a.epilogue == kEpiPosConv) {
         // grouped positional conv: N = 48 outputs per group -> 512 x 64 tile (8 x 1 waves, 3 of 4 column sub-tiles computed)

@@ -273,9 +273,8 @@ void carve_plan(const loco_encoder* e, Plan& p) {
     p.off_x1 = take((size_t)p.M * kHidden * f);
     p.off_tmp = take((size_t)p.M * kHidden * f);
     p.off_ctx = take((size_t)p.M * kHidden * f);
-    // fp32 [M,2304], or (precision f16x3) q and k as fp16 hi|lo planes [M,768] plus V^T planes [B*768, Tp]
-    const size_t Tp = (size_t)((p.T + 63) / 64) * 64;
-    p.off_qkv = take(((size_t)2 * p.M + (size_t)B * Tp) * kHidden * f);
+    // fp32 [M,2304], or (precision f16x3) q, k and v as fp16 hi|lo planes [M,768] each: the same bytes
+    p.off_qkv = take((size_t)3 * p.M * kHidden * f);
     p.off_qp = take((size_t)p.M * kHeads * kRelN * f);
     // FFN intermediate [M,3072]; doubles as scratch for the group-major positional-conv operand [B,16,T+128,48] x 2 planes
     const size_t ffn_elems = (size_t)p.M * e->cfg.ffn, posg_elems = (size_t)B * (p.T + kPosK) * kHidden;
@@ -344,8 +343,8 @@ int run_gemm_split(loco_encoder* e, const Call& c, hipStream_t s, const _Float16
     a.ktaps = ktaps;
     a.terms = (c.precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
-        a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vthi = scatter->Vthi; a.Vtlo = scatter->Vtlo;
-        a.T = scatter->T; a.Tp = scatter->Tp;
+        a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vhi = scatter->Vhi; a.Vlo = scatter->Vlo;
+        a.T = scatter->T;
     }
     a.splitk_ws = c.splitk;
     const double nb = (double)nb1 * nb2;
@@ -577,19 +576,16 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
     float *x0 = bf.x0, *x1 = bf.x1, *tmp = bf.tmp, *qp = bf.qp;
     const int32_t* frames_or_null = bf.frames_or_null;
     const std::string pn = "prenet.", we = "wrapped_encoder.";
-    // q / k planes [M,768] and V^T planes [B*768, Tp] carved from the qkv region; the pad columns t >= T of V^T are
-    // zeroed once per forward (the QKV epilogue never writes them, attention multiplies them by P = 0)
-    const int Tp = ((T + 63) / 64) * 64;
+    // q / k / v as fp16 hi|lo planes [M,768] carved from the qkv region (attention clamps the key rows of its last tile to T - 1
+    // and multiplies them by P = 0: nothing to pad or to zero)
     _Float16* qshi = reinterpret_cast<_Float16*>(bf.qkv);
     _Float16* qslo = qshi + (size_t)M * kHidden;
     GemmSplitArgs scat{};
     scat.Khi = qslo + (size_t)M * kHidden;
     scat.Klo = scat.Khi + (size_t)M * kHidden;
-    scat.Vthi = scat.Klo + (size_t)M * kHidden;
-    scat.Vtlo = scat.Vthi + (size_t)B * kHidden * Tp;
+    scat.Vhi = scat.Klo + (size_t)M * kHidden;
+    scat.Vlo = scat.Vhi + (size_t)M * kHidden;
     scat.T = T;
-    scat.Tp = Tp;
-    HIP_TRY(hipMemsetAsync(scat.Vthi, 0, (size_t)2 * B * kHidden * Tp * sizeof(_Float16), s));
     // a fp32 buffer of n elements holds the two fp16 planes of n elements back to back
     auto planes = [](float* base, size_t n, _Float16*& hi, _Float16*& lo) {
         hi = reinterpret_cast<_Float16*>(base);
@@ -709,8 +705,8 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
             dbg_check(e, s, "q planes lo", l, qslo, (size_t)M * kHidden, true, kHidden);
             dbg_check(e, s, "k planes hi", l, scat.Khi, (size_t)M * kHidden, true, kHidden);
             dbg_check(e, s, "k planes lo", l, scat.Klo, (size_t)M * kHidden, true, kHidden);
-            dbg_check(e, s, "v^T planes hi", l, scat.Vthi, (size_t)B * kHidden * Tp, true, Tp);
-            dbg_check(e, s, "v^T planes lo", l, scat.Vtlo, (size_t)B * kHidden * Tp, true, Tp);
+            dbg_check(e, s, "v planes hi", l, scat.Vhi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "v planes lo", l, scat.Vlo, (size_t)M * kHidden, true, kHidden);
         }
         // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320] is computed INSIDE the attention kernel (attention_f16x3.hip,
         // TABLE form): `qp` is scratch of that launch; no table GEMM runs any more.
@@ -720,8 +716,8 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
             // algorithmic bytes: q|k|v in, context out -- the table is now an internal scratch of the launch, not compulsory traffic
             Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim + 2.0 * M * (double)kHeads * kRelN * kHeadDim,
                        4.0 * (M * (double)(kQkv + kHidden)));
-            HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vthi, scat.Vtlo, qp, frames_or_null, chi, clo, nullptr, B, T,
-                                           Tp, s, e->pe_s.hi, e->pe_s.lo, e->pe_s.inv_scale));
+            HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vhi, scat.Vlo, qp, frames_or_null, chi, clo, nullptr, B, T,
+                                           s, e->pe_s.hi, e->pe_s.lo, e->pe_s.inv_scale));
         }
         if (e->debug_nonfinite) {
             dbg_check(e, s, "attention context planes hi", l, chi, (size_t)M * kHidden, true, kHidden);
@@ -1506,7 +1502,6 @@ int loco_op_pos_conv(const float* h, const float* w_folded, const float* bias, c
     return LOCO_OK;
 }
 
-int32_t loco_op_vt_column(int32_t t) { return loco::vt_col(t); }
 
 size_t loco_normalize_scratch_bytes(int32_t B) { return B > 0 ? normalize_scratch_bytes(B) : 0; }
 
@@ -1598,22 +1593,22 @@ int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, con
     return LOCO_OK;
 }
 
-int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
-                            const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T, int32_t Tp, void* stream) {
-    if (!qhi || !qlo || !khi || !klo || !vthi || !vtlo || !qp || !ctx) return fail(LOCO_E_INVALID, "loco_op_attention_f16x3: null argument");
+int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vhi, const void* vlo,
+                            const float* qp, const int32_t* frames, float* ctx, int32_t B, int32_t T, void* stream) {
+    if (!qhi || !qlo || !khi || !klo || !vhi || !vlo || !qp || !ctx) return fail(LOCO_E_INVALID, "loco_op_attention_f16x3: null argument");
     HIP_TRY(launch_attention_f16x3((const _Float16*)qhi, (const _Float16*)qlo, (const _Float16*)khi, (const _Float16*)klo,
-                                   (const _Float16*)vthi, (const _Float16*)vtlo, qp, frames, nullptr, nullptr, ctx, B, T, Tp,
+                                   (const _Float16*)vhi, (const _Float16*)vlo, qp, frames, nullptr, nullptr, ctx, B, T,
                                    (hipStream_t)stream));
     return LOCO_OK;
 }
 
-int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vthi, const void* vtlo,
+int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vhi, const void* vlo,
                                const void* pe_hi, const void* pe_lo, float pe_scale, float* qp_scratch, const int32_t* frames, float* ctx,
-                               int32_t B, int32_t T, int32_t Tp, void* stream) {
-    if (!qhi || !qlo || !khi || !klo || !vthi || !vtlo || !pe_hi || !pe_lo || !qp_scratch || !ctx)
+                               int32_t B, int32_t T, void* stream) {
+    if (!qhi || !qlo || !khi || !klo || !vhi || !vlo || !pe_hi || !pe_lo || !qp_scratch || !ctx)
         return fail(LOCO_E_INVALID, "loco_op_attention_f16x3_pe: null argument");
     HIP_TRY(launch_attention_f16x3((const _Float16*)qhi, (const _Float16*)qlo, (const _Float16*)khi, (const _Float16*)klo,
-                                   (const _Float16*)vthi, (const _Float16*)vtlo, qp_scratch, frames, nullptr, nullptr, ctx, B, T, Tp,
+                                   (const _Float16*)vhi, (const _Float16*)vlo, qp_scratch, frames, nullptr, nullptr, ctx, B, T,
                                    (hipStream_t)stream, (const _Float16*)pe_hi, (const _Float16*)pe_lo, pe_scale));
     return LOCO_OK;
 }

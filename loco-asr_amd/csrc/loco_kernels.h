@@ -57,8 +57,7 @@ struct GemmSplitArgs {
     long sA1, sA2, sC1, sC2;
     int epilogue;
     // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
-    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vthi/Vtlo transposed per head: [(b*12+head)*64+d][Tp],
-    // frame t in column vt_col(t)
+    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vhi/Vlo [M,768] (attention transposes V with its LDS read)
     // kEpiResidual: the residual may also be given as fp16 hi/lo planes (same element offsets and ldr as R); it is then hi + lo,
     // exact in fp32.  The encoder's residual stream lives only in that form between layers (LayerNorm writes no fp32 copy).
     const _Float16* Rhi = nullptr;
@@ -67,9 +66,9 @@ struct GemmSplitArgs {
     float* splitk_ws = nullptr;
     _Float16* Khi = nullptr;
     _Float16* Klo = nullptr;
-    _Float16* Vthi = nullptr;
-    _Float16* Vtlo = nullptr;
-    int T = 0, Tp = 0;
+    _Float16* Vhi = nullptr;
+    _Float16* Vlo = nullptr;
+    int T = 0;
     // kEpiPosConv (grouped positional conv as a GEMM over the group-major halo layout, see launch_group_major_split):
     // z1 = clip, z2 = group; C = R + GELU(acc + bias) + sin_table[pos(t)], pos = t+2 for t < frames[z1] else 1
     // The weight planes hold W * 2^k (k chosen per tensor at load time so that max|W| lands in [2^13, 2^14): fp16's 5-bit
@@ -108,8 +107,8 @@ hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, i
 // folded positional-conv weight [g][tap][o][i] -> [g][o][tap*48 + i] (the GEMM's W, ldw = 6144)
 hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s);
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
-                                  const _Float16* vthi, const _Float16* vtlo, const float* qp, const int32_t* frames,
-                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, int Tp, hipStream_t s,
+                                  const _Float16* vhi, const _Float16* vlo, const float* qp, const int32_t* frames,
+                                  _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, hipStream_t s,
                                   const _Float16* pe_hi = nullptr, const _Float16* pe_lo = nullptr, float pe_scale = 1.0f);
 // pe_hi / pe_lo != nullptr: the relative-position table is COMPUTED by the kernel (Qp = q . pe_k^T * pe_scale, pe planes [320][64])
 // into `qp`, which is then scratch of the launch ([B,12,T,320] fp32) instead of an input.
@@ -188,13 +187,6 @@ __device__ __forceinline__ void range_commit_block(float* slot, float amax, unsi
 }
 
 // exact GELU 0.5*x*(1+erf(x/sqrt2))
-// Column of frame t in a V^T plane row: bits 2 and 3 of t are swapped, i.e. each aligned group of 16 frames is stored as
-// [0-3, 8-11, 4-7, 12-15].  The split-precision attention feeds P straight from the S^T accumulator registers into the
-// next MFMA as its B operand; a lane half then holds keys {4h..4h+3, 8+4h..8+4h+3} of a 16-key k-step, and with this
-// column order the matching V^T fragment is ONE contiguous 16-byte piece (attention_f16x3.hip).  (The 16x16x32 MFMA
-// shape was built too -- it wants bits (b4 b3 b2) -> (b3 b2 b4) inside groups of 32 -- and ran only 2 % faster: this
-// kernel is not limited by the matrix pipe's power the way the GEMM is, so the simpler 32x32x16 form stays.)
-__host__ __device__ __forceinline__ int vt_col(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 
 // Exact (erf) GELU, HF transformers/activations.py:83-89, without erff's two divergent branches.
 //   erfc(t) = exp(-t q(t)) for t >= 0 with q(t) = -ln(erfc(t)) / t smooth and slowly varying (q(0) = 2/sqrt(pi)); with

@@ -25,12 +25,12 @@ class Attention:
     workgroups of other kernels fit beside it on the same CU)."""
 
     def __init__(self, B=16, T=1499):
-        self.B, self.T, self.Tp = B, T, (T + 63) // 64 * 64
+        self.B, self.T = B, T
         M = B * T
         g = torch.Generator(device="cuda").manual_seed(3)
         rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).half()
         self.q, self.k = [rn(M, 768, sc=s_) for s_ in (0.2, 2e-4)], [rn(M, 768, sc=s_) for s_ in (1.0, 1e-3)]
-        self.v = [rn(B * 768, self.Tp, sc=s_) for s_ in (1.0, 1e-3)]
+        self.v = [rn(B * T, 768, sc=s_) for s_ in (1.0, 1e-3)]
         self.qp = torch.randn(B, 12, T, 320, device="cuda", generator=g) * 0.5
         self.ctx = torch.empty(B, T, 768, device="cuda")
 
@@ -38,7 +38,7 @@ class Attention:
         st = C.c_void_p(stream.cuda_stream)
         for _ in range(reps):
             check(lib().loco_op_attention_f16x3(ptr(self.q[0]), ptr(self.q[1]), ptr(self.k[0]), ptr(self.k[1]), ptr(self.v[0]), ptr(self.v[1]),
-                                                ptr(self.qp), None, ptr(self.ctx), self.B, self.T, self.Tp, st))
+                                                ptr(self.qp), None, ptr(self.ctx), self.B, self.T, st))
 
 
 def beside_attention(launch, out, trials=4, reps_attention=10, reps_victim=3):

@@ -284,21 +284,14 @@ def test_attention_core_f16x3(B, T, frames, oracle):
     k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
     v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
     qp = (q @ pe_k.t()).contiguous()
-    Tp = (T + 63) // 64 * 64
     qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp)
-    vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)  # [B, head*64+d, t]
-    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
-    vtp = torch.zeros_like(vt)
-    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
-    vt = vtp
-    vh, vl = planes(vt.reshape(B * 768, Tp))
+    vh, vl = planes(qkv[..., 1536:].reshape(B * T, 768))  # row-major like q and k: the kernel transposes V with its LDS read
     fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
     frd = fr.cuda() if fr is not None else None
     qpd = dev(qp)
     ctx = torch.empty(B, T, 768, device="cuda")
-    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), ptr(frd), ptr(ctx), B, T, Tp, stream()))
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), ptr(frd), ptr(ctx), B, T, stream()))
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None if fr is None else fr.long(), q_block=128)
     ref = ref.transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 1e-5
@@ -316,20 +309,16 @@ def test_attention_f16x3_computes_the_relative_position_table_itself(B, T, frame
     q = qkv[..., :768].view(B, T, 12, 64).transpose(1, 2)
     k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
     v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
-    Tp = (T + 63) // 64 * 64
     qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp)
-    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
-    vt[:, :, col[:T]] = qkv[..., 1536:].transpose(1, 2)
-    vh, vl = planes(vt.reshape(B * 768, Tp))
+    vh, vl = planes(qkv[..., 1536:].reshape(B * T, 768))
     ph, pl_ = planes(pe_k * 512.0)
     fr = None if frames is None else torch.tensor(frames, dtype=torch.int32)
     frd = fr.cuda() if fr is not None else None
     scratch = torch.full((B, 12, T, 320), float("nan"), device="cuda")
     ctx = torch.empty(B, T, 768, device="cuda")
     check(lib().loco_op_attention_f16x3_pe(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(ph), ptr(pl_), 1.0 / 512.0, ptr(scratch),
-                                           ptr(frd), ptr(ctx), B, T, Tp, stream()))
+                                           ptr(frd), ptr(ctx), B, T, stream()))
     # the operands the kernel really multiplies: q and pe_k as their hi + lo planes
     qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2).cpu()
     ped = ((ph.double() + pl_.double()) / 512.0).cpu()
@@ -337,7 +326,7 @@ def test_attention_f16x3_computes_the_relative_position_table_itself(B, T, frame
     ref = oracle.attention_core(qd, k.double(), v.double(), ped, None if fr is None else fr.long(), q_block=128).transpose(1, 2).reshape(B, T, 768)
     assert bool(torch.isfinite(ctx).all()) and rel_l2(ctx, ref) < 1e-5
     ctx2 = torch.empty_like(ctx)
-    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(scratch), ptr(frd), ptr(ctx2), B, T, Tp, stream()))
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(scratch), ptr(frd), ptr(ctx2), B, T, stream()))
     assert torch.equal(ctx, ctx2)  # same table, same kernel body: the two forms agree bit for bit
 
 
@@ -367,16 +356,12 @@ def test_attention_f16x3_row_max_covers_both_lane_halves(key, gap, oracle):
     k = qkv[..., 768:1536].view(B, T, 12, 64).transpose(1, 2)
     v = qkv[..., 1536:].view(B, T, 12, 64).transpose(1, 2)
     qp = (q @ pe_k.t()).contiguous()
-    Tp = (T + 63) // 64 * 64
     qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp)
-    col = torch.tensor([lib().loco_op_vt_column(t) for t in range(Tp)])
-    vt[:, :, col[:T]] = qkv[..., 1536:].transpose(1, 2)
-    vh, vl = planes(vt.reshape(B * 768, Tp))
+    vh, vl = planes(qkv[..., 1536:].reshape(B * T, 768))
     qpd = dev(qp)
     ctx = torch.empty(B, T, 768, device="cuda")
-    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), None, ptr(ctx), B, T, Tp, stream()))
+    check(lib().loco_op_attention_f16x3(ptr(qh), ptr(ql), ptr(kh), ptr(kl), ptr(vh), ptr(vl), ptr(qpd), None, ptr(ctx), B, T, stream()))
     assert bool(torch.isfinite(ctx).all()), f"{int((~torch.isfinite(ctx)).any(-1).sum())} rows are not finite"
     ref = oracle.attention_core(q.double(), k.double(), v.double(), pe_k.double(), None, q_block=128).transpose(1, 2).reshape(B, T, 768)
     assert rel_l2(ctx, ref) < 1e-5

@@ -7,7 +7,7 @@ la = importlib.import_module("loco-asr_amd")
 lib = la._lib.load()
 if len(sys.argv) > 1:  # A/B another build of the library inside the same process (same device, same clocks)
     alt = C.CDLL(os.path.abspath(sys.argv[1]))
-    for name in ("loco_op_attention_f16x3", "loco_op_vt_column"):
+    for name in ("loco_op_attention_f16x3",):
         getattr(alt, name).restype = getattr(lib, name).restype
         getattr(alt, name).argtypes = getattr(lib, name).argtypes
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -28,20 +28,14 @@ def run(B, T, reps, check=False, ragged=False, use_alt=False):
     Tp = (T + 63) // 64 * 64
     qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp, device="cuda")
-    vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)
-    col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
-    vtp = torch.zeros_like(vt)
-    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
-    vt = vtp
-    vh, vl = planes(vt.reshape(B * 768, Tp))
+    vh, vl = planes(qkv[..., 1536:].reshape(B * T, 768))  # row-major like q and k
     fr = None
     if ragged:
         fr = torch.tensor([T - (i * 37) % (T // 2) for i in range(B)], dtype=torch.int32, device="cuda")
     ctx = torch.empty(B, T, 768, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     L = alt if use_alt else lib
-    call = lambda: L.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st)
+    call = lambda: L.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, st)
     assert call() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -55,7 +49,7 @@ def run(B, T, reps, check=False, ragged=False, use_alt=False):
     if check:
         qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2)
         kd = (kh.double() + kl.double()).view(B, T, 12, 64).transpose(1, 2)
-        vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., col][..., :T].transpose(2, 3)
+        vd = (vh.double() + vl.double()).view(B, T, 12, 64).transpose(1, 2)
         i = torch.arange(T, device="cuda")
         rel = (i[:, None] - i[None, :]).clamp(-160, 159) + 160
         bias = torch.gather(qp.double(), 3, rel[None, None].expand(B, 12, T, T))

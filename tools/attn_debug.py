@@ -19,21 +19,15 @@ def run(B, T, nvalid=None, zero_bias=False):
     Tp = (T + 63) // 64 * 64
     qh, ql = planes(qkv[..., :768].reshape(B * T, 768))
     kh, kl = planes(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp, device="cuda")
-    vt[:, :, :T] = qkv[..., 1536:].transpose(1, 2)
-    col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
-    vtp = torch.zeros_like(vt)
-    vtp[:, :, col] = vt  # frame t lives in column loco_op_vt_column(t)
-    vt = vtp
-    vh, vl = planes(vt.reshape(B * 768, Tp))
+    vh, vl = planes(qkv[..., 1536:].reshape(B * T, 768))  # row-major like q and k
     fr = None if nvalid is None else torch.tensor(nvalid, dtype=torch.int32, device="cuda")
     ctx = torch.zeros(B, T, 768, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st) == 0
+    assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, st) == 0
     torch.cuda.synchronize()
     qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2)
     kd = (kh.double() + kl.double()).view(B, T, 12, 64).transpose(1, 2)
-    vd = (vh.double() + vl.double()).view(B, 12, 64, Tp)[..., col][..., :T].transpose(2, 3)
+    vd = (vh.double() + vl.double()).view(B, T, 12, 64).transpose(1, 2)
     i = torch.arange(T, device="cuda")
     rel = (i[:, None] - i[None, :]).clamp(-160, 159) + 160
     s = qd @ kd.transpose(2, 3) + torch.gather(qp.double(), 3, rel[None, None].expand(B, 12, T, T))

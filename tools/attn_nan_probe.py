@@ -31,7 +31,6 @@ v0 = F.linear(h0, w("attention.v_proj.weight"), w("attention.v_proj.bias"))
 pe = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"]).cuda()
 pl = lambda t: (t.half().contiguous(), (t - t.half().float()).half().contiguous())
 Tp = (T + 63) // 64 * 64
-col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
 nqb = (T + 127) // 128
 nblk = nqb * 12 * B
 
@@ -40,10 +39,8 @@ def run(q, k, v, which, label):
     qp = (q.view(B, T, 12, 64).transpose(1, 2) @ pe.t()).contiguous()
     ctx = torch.empty(B, T, 768, device="cuda")
     qh, ql = pl(q.reshape(B * T, 768)); kh, kl = pl(k.reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp, device="cuda")
-    vt[:, :, col[:T]] = v.transpose(1, 2)
-    vh, vl = pl(vt.reshape(B * 768, Tp))
-    assert which.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, Tp, st()) == 0
+    vh, vl = pl(v.reshape(B * T, 768))
+    assert which.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, st()) == 0
     torch.cuda.synchronize()
     bad = (~torch.isfinite(ctx)).view(B, T, 12, 64).any(-1).nonzero()
     print(f"{label:50s}: {len(bad):3d} non-finite (row, head) pairs {bad[:10, 1:].tolist()}", flush=True)

@@ -25,7 +25,7 @@ torch.manual_seed(0)
 M = B * T
 q = [(torch.randn(M, 768, device="cuda") * s_).half() for s_ in (0.2, 2e-4)]
 k = [(torch.randn(M, 768, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
-v = [(torch.randn(B * 768, Tp, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
+v = [(torch.randn(M, 768, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
 qp = torch.randn(B, 12, T, 320, device="cuda") * 0.5
 pe = [(torch.randn(320, 64, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
 ctx = torch.empty(B, T, 768, device="cuda")
@@ -37,10 +37,10 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run():
     if TABLE:
         L_.check(lib.loco_op_attention_f16x3_pe(q[0].data_ptr(), q[1].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), v[0].data_ptr(), v[1].data_ptr(),
-                                                 pe[0].data_ptr(), pe[1].data_ptr(), 0.5, qp.data_ptr(), None, ctx.data_ptr(), B, T, Tp, st))
+                                                 pe[0].data_ptr(), pe[1].data_ptr(), 0.5, qp.data_ptr(), None, ctx.data_ptr(), B, T, st))
         return
     L_.check(lib.loco_op_attention_f16x3(q[0].data_ptr(), q[1].data_ptr(), k[0].data_ptr(), k[1].data_ptr(), v[0].data_ptr(), v[1].data_ptr(),
-                                          qp.data_ptr(), None, ctx.data_ptr(), B, T, Tp, st))
+                                          qp.data_ptr(), None, ctx.data_ptr(), B, T, st))
 
 
 for _ in range(3):

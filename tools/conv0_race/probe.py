@@ -109,7 +109,7 @@ Tp = (Ta + 63) // 64 * 64
 Ma = B * Ta
 aq = [(torch.randn(Ma, 768, device="cuda") * s_).half() for s_ in (0.2, 2e-4)]
 ak = [(torch.randn(Ma, 768, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
-av = [(torch.randn(B * 768, Tp, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
+av = [(torch.randn(B * Ta, 768, device="cuda") * s_).half() for s_ in (1.0, 1e-3)]
 aqp = torch.randn(B, 12, Ta, 320, device="cuda") * 0.5
 actx = torch.empty(B, Ta, 768, device="cuda")
 
@@ -118,7 +118,7 @@ def attention_corunner(stream, reps):
     st = C.c_void_p(stream.cuda_stream)
     for _ in range(reps):
         L_.check(lib.loco_op_attention_f16x3(aq[0].data_ptr(), aq[1].data_ptr(), ak[0].data_ptr(), ak[1].data_ptr(), av[0].data_ptr(), av[1].data_ptr(),
-                                              aqp.data_ptr(), None, actx.data_ptr(), B, Ta, Tp, st))
+                                              aqp.data_ptr(), None, actx.data_ptr(), B, Ta, st))
 
 
 MODES = [a[2:] for a in sys.argv[1:] if a.startswith("--")] or ["solo", "busy", "attention"]

@@ -19,7 +19,7 @@ M = B * T
 g = torch.Generator(device="cuda").manual_seed(3)
 rn = lambda *s, sc=1.0: (torch.randn(*s, device="cuda", generator=g) * sc).half()
 q, k = [rn(M, 768, sc=s_) for s_ in (0.2, 2e-4)], [rn(M, 768, sc=s_) for s_ in (1.0, 1e-3)]
-v = [rn(B * 768, Tp, sc=s_) for s_ in (1.0, 1e-3)]
+v = [rn(B * T, 768, sc=s_) for s_ in (1.0, 1e-3)]
 qp = torch.randn(B, 12, T, 320, device="cuda", generator=g) * 0.5
 ctx = torch.empty(B, T, 768, device="cuda")
 rows = 16 * 1499 * 8
@@ -36,7 +36,7 @@ x0 = x.clone()
 for trial in range(4):
     out.zero_(); torch.cuda.synchronize()
     for _ in range(10):
-        assert agg.loco_op_attention_f16x3(ptr(q[0]), ptr(q[1]), ptr(k[0]), ptr(k[1]), ptr(v[0]), ptr(v[1]), ptr(qp), None, ptr(ctx), B, T, Tp, C.c_void_p(sb.cuda_stream)) == 0
+        assert agg.loco_op_attention_f16x3(ptr(q[0]), ptr(q[1]), ptr(k[0]), ptr(k[1]), ptr(v[0]), ptr(v[1]), ptr(qp), None, ptr(ctx), B, T, C.c_void_p(sb.cuda_stream)) == 0
     for _ in range(6):
         ln(sa)
     torch.cuda.synchronize()

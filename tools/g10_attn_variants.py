@@ -25,7 +25,6 @@ v0 = F.linear(h0, w("attention.v_proj.weight"), w("attention.v_proj.bias"))
 pe = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"]).cuda()
 pl = lambda t: (t.half().contiguous(), (t - t.half().float()).half().contiguous())
 Tp = (T + 63) // 64 * 64
-col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
 
 
 def run(q, k, v, qp_scale=1.0, label="", f32=False, lo_zero=False):
@@ -36,12 +35,10 @@ def run(q, k, v, qp_scale=1.0, label="", f32=False, lo_zero=False):
         assert lib.loco_op_attention(P(qkv), P(qp), None, P(ctx), B, T, st()) == 0
     else:
         qh, ql = pl(q.reshape(B * T, 768)); kh, kl = pl(k.reshape(B * T, 768))
-        vt = torch.zeros(B, 768, Tp, device="cuda")
-        vt[:, :, col[:T]] = v.transpose(1, 2)
-        vh, vl = pl(vt.reshape(B * 768, Tp))
+        vh, vl = pl(v.reshape(B * T, 768))
         if lo_zero:
             ql.zero_(); kl.zero_(); vl.zero_()
-        assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, Tp, st()) == 0
+        assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, st()) == 0
     torch.cuda.synchronize()
     bad = (~torch.isfinite(ctx)).view(B, T, 12, 64).any(-1).nonzero()
     print(f"{label:58s}: {len(bad):3d} non-finite (row, head) pairs {bad[:6, 1:].tolist()}", flush=True)

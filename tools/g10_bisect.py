@@ -46,13 +46,10 @@ qp = (q.view(B, T, 12, 64).transpose(1, 2) @ pe.t()).contiguous()
 pl = lambda t: (t.half().contiguous(), (t - t.half().float()).half().contiguous())
 Tp = (T + 63) // 64 * 64
 qh, ql = pl(q.reshape(B * T, 768)); kh, kl = pl(k.reshape(B * T, 768))
-vt = torch.zeros(B, 768, Tp, device="cuda")
-col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
-vt[:, :, col[:T]] = v.transpose(1, 2)
-vh, vl = pl(vt.reshape(B * 768, Tp))
+vh, vl = pl(v.reshape(B * T, 768))
 ctx = torch.empty(B, T, 768, device="cuda")
 for fr, label in ((frames, "with the frame counts"), (None, "without mask")):
-    assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, Tp, st()) == 0
+    assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), P(fr), P(ctx), B, T, st()) == 0
     torch.cuda.synchronize()
     ref = oracle.attention_core(q.view(B, T, 12, 64).transpose(1, 2).double().cpu(), k.view(B, T, 12, 64).transpose(1, 2).double().cpu(),
                                 v.view(B, T, 12, 64).transpose(1, 2).double().cpu(), pe.double().cpu(), None if fr is None else fr.long().cpu(), q_block=128)

@@ -110,15 +110,12 @@ def attention_phase(B, T):
     pl = lambda x: (x.half().contiguous(), (x - x.half().float()).half().contiguous())  # noqa: E731
     qh, ql = pl(qkv[..., :768].reshape(B * T, 768))
     kh, kl = pl(qkv[..., 768:1536].reshape(B * T, 768))
-    vt = torch.zeros(B, 768, Tp, device="cuda")
-    col = torch.tensor([lib.loco_op_vt_column(t) for t in range(Tp)], device="cuda")
-    vt[:, :, col[:T]] = qkv[..., 1536:].transpose(1, 2)
-    vh, vl = pl(vt.reshape(B * 768, Tp))
+    vh, vl = pl(qkv[..., 1536:].reshape(B * T, 768))
     ctx = torch.empty(B, T, 768, device="cuda")
-    del qkv, vt
+    del qkv
 
     def call():
-        assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, Tp, st) == 0
+        assert lib.loco_op_attention_f16x3(P(qh), P(ql), P(kh), P(kl), P(vh), P(vl), P(qp), None, P(ctx), B, T, st) == 0
     loop(f"attention_f16x3 B={B} T={T}", call, 4.0 * B * 12 * T * T * 64, 3)
 
 
