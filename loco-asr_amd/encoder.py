@@ -296,6 +296,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
     def _sync_weights(self, device: torch.device, min_sin_rows: int):
         stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         if self._weights_dirty:
+            self.drain()  # forwards still in flight on the slots' streams read the planes that are about to be rebuilt
             for prefix, mod in (("prenet.", self.prenet), ("wrapped_encoder.", self.wrapped_encoder)):
                 for name, p in mod.state_dict().items():
                     t = p.detach()

@@ -215,3 +215,32 @@ def test_the_sinusoid_table_may_grow_while_other_forwards_are_in_flight():
     torch.cuda.synchronize()
     assert torch.equal(b["outs"][1], b["outs"][0]) and bool(torch.isfinite(b["outs"][0]).all())
     assert rel_l2(a["outs"][1], a["outs"][0]) < 1e-6
+
+
+def test_load_state_dict_with_forwards_in_flight_finishes_them_on_the_old_weights():
+    """A second load_state_dict rebuilds the split planes in place.  Forwards enqueued before it must have finished on the OLD weights
+    by then (the module drains its slots before it touches the handle), and the forwards after it use the new ones."""
+    layers = 2
+    sd_a = la.synth.encoder_state_dict(0, layers=layers)
+    sd_b = la.synth.encoder_state_dict(1, layers=layers)
+
+    def fresh(sd):
+        pre, enc_sd = la.synth.split_state_dict(sd)
+        return la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                                 {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=layers).cuda().speecht5.encoder
+
+    batches = _pairs(6, seconds=4.0, seed_base=300)
+    ref_a = [fresh(sd_a)(input_values=x, attention_mask=a).last_hidden_state.clone() for x, a in batches]
+    ref_b = [fresh(sd_b)(input_values=x, attention_mask=a).last_hidden_state.clone() for x, a in batches]
+    assert not torch.equal(ref_a[0], ref_b[0])
+    enc = fresh(sd_a)
+    enc.set_inflight(4)
+    first = [enc.forward_async(input_values=x, attention_mask=a) for x, a in batches[:4]]   # in flight on weights A
+    pre_b, enc_b = la.synth.split_state_dict(sd_b)
+    enc.prenet.load_state_dict({k: torch.from_numpy(v) for k, v in pre_b.items()})
+    enc.wrapped_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in enc_b.items()})
+    second = [enc.forward_async(input_values=x, attention_mask=a) for x, a in batches]       # weights B
+    for t, r in zip(first, ref_a):
+        assert torch.equal(t.result().last_hidden_state, r)
+    for t, r in zip(second, ref_b):
+        assert torch.equal(t.result().last_hidden_state, r)
