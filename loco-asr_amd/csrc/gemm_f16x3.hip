@@ -74,15 +74,11 @@ __device__ __forceinline__ void split_gemm_store(const GemmSplitArgs& p, f32x4 v
     }
     const h4 hi = __builtin_bit_cast(h4, hu), lo = __builtin_bit_cast(h4, lu);
     if (EPI == kEpiQkvScatter) {
-        if (n < kHidden) {  // q
-            *reinterpret_cast<h4*>(p.Chi + (long)m * kHidden + n) = hi;
-            *reinterpret_cast<h4*>(p.Clo + (long)m * kHidden + n) = lo;
-        } else if (n < 2 * kHidden) {  // k
-            *reinterpret_cast<h4*>(p.Khi + (long)m * kHidden + n - kHidden) = hi;
-            *reinterpret_cast<h4*>(p.Klo + (long)m * kHidden + n - kHidden) = lo;
-        } else {  // v: row-major like q and k (attention transposes it with ds_read_b64_tr_b16)
-            *reinterpret_cast<h4*>(p.Vhi + (long)m * kHidden + n - 2 * kHidden) = hi;
-            *reinterpret_cast<h4*>(p.Vlo + (long)m * kHidden + n - 2 * kHidden) = lo;
+        {  // q | k | v: the three plane pairs are qkv_stride apart (launch_gemm_split checks it), v row-major like q and k
+            const int third = n < kHidden ? 0 : (n < 2 * kHidden ? 1 : 2);
+            const long o = third * p.qkv_stride + (long)m * kHidden + (n - third * kHidden);
+            *reinterpret_cast<h4*>(p.Chi + o) = hi;
+            *reinterpret_cast<h4*>(p.Clo + o) = lo;
         }
     } else {
         const long o = coff + (long)m * p.ldc + n;
@@ -149,9 +145,9 @@ __device__ __forceinline__ void split_gemm_store16(const GemmSplitArgs& p, f32x4
     _Float16 *dh, *dl;
     if (EPI == kEpiQkvScatter) {
         const int third = n < kHidden ? 0 : (n < 2 * kHidden ? 1 : 2);  // a run of 16 columns never straddles q | k | v (768 = 48 x 16)
-        const long o = (long)m * kHidden + (n - third * kHidden);
-        dh = (third == 0 ? p.Chi : third == 1 ? p.Khi : p.Vhi) + o;
-        dl = (third == 0 ? p.Clo : third == 1 ? p.Klo : p.Vlo) + o;
+        const long o = third * p.qkv_stride + (long)m * kHidden + (n - third * kHidden);  // the plane pairs are qkv_stride apart
+        dh = p.Chi + o;
+        dl = p.Clo + o;
     } else {
         const long o = coff + (long)m * p.ldc + n;
         dh = p.Chi + o;
@@ -655,8 +651,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_qkv_kernel(GemmSplitArgs p,
     const int n = n0 + 4 * c4;
     const f32x4 bias = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int third = n0 < kHidden ? 0 : (n0 < 2 * kHidden ? 1 : 2);  // block-uniform: 768 = 12 x 64
-    _Float16* const dh = third == 0 ? p.Chi : third == 1 ? p.Khi : p.Vhi;
-    _Float16* const dl = third == 0 ? p.Clo : third == 1 ? p.Klo : p.Vlo;
+    _Float16* const dh = p.Chi + third * p.qkv_stride;
+    _Float16* const dl = p.Clo + third * p.qkv_stride;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int ml = r0 + 16 * rr, m = m0 + ml;
@@ -767,7 +763,7 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     const bool split = a.Chi != nullptr;
     if (split ? (a.Clo == nullptr) : (a.C == nullptr)) return hipErrorInvalidValue;
     if (a.epilogue == kEpiQkvScatter &&
-        (!split || !a.Khi || !a.Klo || !a.Vhi || !a.Vlo || a.N != kQkv || a.nb1 * a.nb2 != 1))
+        (!split || a.N != kQkv || a.nb1 * a.nb2 != 1 || a.qkv_stride < (long)a.M * kHidden))
         return hipErrorInvalidValue;
     if (a.epilogue == kEpiPosConv) {
         // grouped positional conv: N = 48 outputs per group -> 512 x 64 tile (8 x 1 waves, 3 of 4 column sub-tiles computed)

@@ -343,7 +343,7 @@ int run_gemm_split(loco_encoder* e, const Call& c, hipStream_t s, const _Float16
     a.ktaps = ktaps;
     a.terms = (c.precision == 2 && kid != K_QP) ? 2 : 3;  // the relative-position table keeps all three terms (K = 64: it costs nothing)
     if (scatter) {
-        a.Khi = scatter->Khi; a.Klo = scatter->Klo; a.Vhi = scatter->Vhi; a.Vlo = scatter->Vlo;
+        a.qkv_stride = scatter->qkv_stride;
         a.T = scatter->T;
     }
     a.splitk_ws = c.splitk;
@@ -580,11 +580,13 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
     // and multiplies them by P = 0: nothing to pad or to zero)
     _Float16* qshi = reinterpret_cast<_Float16*>(bf.qkv);
     _Float16* qslo = qshi + (size_t)M * kHidden;
+    // planes in the order q_hi, q_lo, k_hi, k_lo, v_hi, v_lo: the k and v pairs sit 2 M 768 halves behind the pair before them
+    _Float16* const kshi = qslo + (size_t)M * kHidden;
+    _Float16* const kslo = kshi + (size_t)M * kHidden;
+    _Float16* const vshi = kslo + (size_t)M * kHidden;
+    _Float16* const vslo = vshi + (size_t)M * kHidden;
     GemmSplitArgs scat{};
-    scat.Khi = qslo + (size_t)M * kHidden;
-    scat.Klo = scat.Khi + (size_t)M * kHidden;
-    scat.Vhi = scat.Klo + (size_t)M * kHidden;
-    scat.Vlo = scat.Vhi + (size_t)M * kHidden;
+    scat.qkv_stride = (long)2 * M * kHidden;
     scat.T = T;
     // a fp32 buffer of n elements holds the two fp16 planes of n elements back to back
     auto planes = [](float* base, size_t n, _Float16*& hi, _Float16*& lo) {
@@ -703,10 +705,10 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
             dbg_check(e, s, "x0 planes lo (layer input)", l, x0lo, (size_t)M * kHidden, true, kHidden);
             dbg_check(e, s, "q planes hi", l, qshi, (size_t)M * kHidden, true, kHidden);
             dbg_check(e, s, "q planes lo", l, qslo, (size_t)M * kHidden, true, kHidden);
-            dbg_check(e, s, "k planes hi", l, scat.Khi, (size_t)M * kHidden, true, kHidden);
-            dbg_check(e, s, "k planes lo", l, scat.Klo, (size_t)M * kHidden, true, kHidden);
-            dbg_check(e, s, "v planes hi", l, scat.Vhi, (size_t)M * kHidden, true, kHidden);
-            dbg_check(e, s, "v planes lo", l, scat.Vlo, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "k planes hi", l, kshi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "k planes lo", l, kslo, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "v planes hi", l, vshi, (size_t)M * kHidden, true, kHidden);
+            dbg_check(e, s, "v planes lo", l, vslo, (size_t)M * kHidden, true, kHidden);
         }
         // Qp[b,h] = q_scaled[b,:,h,:] pe_k^T -> fp32 [B,12,T,320] is computed INSIDE the attention kernel (attention_f16x3.hip,
         // TABLE form): `qp` is scratch of that launch; no table GEMM runs any more.
@@ -716,7 +718,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
             // algorithmic bytes: q|k|v in, context out -- the table is now an internal scratch of the launch, not compulsory traffic
             Bracket br(e, s, K_ATTN_SPLIT, 4.0 * B * kHeads * tt * kHeadDim + 2.0 * M * (double)kHeads * kRelN * kHeadDim,
                        4.0 * (M * (double)(kQkv + kHidden)));
-            HIP_TRY(launch_attention_f16x3(qshi, qslo, scat.Khi, scat.Klo, scat.Vhi, scat.Vlo, qp, frames_or_null, chi, clo, nullptr, B, T,
+            HIP_TRY(launch_attention_f16x3(qshi, qslo, kshi, kslo, vshi, vslo, qp, frames_or_null, chi, clo, nullptr, B, T,
                                            s, e->pe_s.hi, e->pe_s.lo, e->pe_s.inv_scale));
         }
         if (e->debug_nonfinite) {

@@ -57,17 +57,15 @@ struct GemmSplitArgs {
     long sA1, sA2, sC1, sC2;
     int epilogue;
     // kEpiQkvScatter (fused q|k|v projection feeding the split-precision attention): columns [0,768) -> Chi/Clo planes
-    // [M,768] (q), [768,1536) -> Khi/Klo [M,768], [1536,2304) -> Vhi/Vlo [M,768] (attention transposes V with its LDS read)
+    // [M,768] (q), [768,1536) -> the k planes, [1536,2304) -> the v planes, each pair qkv_stride halves behind the previous one (attention
+    // transposes V with its LDS read)
     // kEpiResidual: the residual may also be given as fp16 hi/lo planes (same element offsets and ldr as R); it is then hi + lo,
     // exact in fp32.  The encoder's residual stream lives only in that form between layers (LayerNorm writes no fp32 copy).
     const _Float16* Rhi = nullptr;
     const _Float16* Rlo = nullptr;
     // split-K for small problems (launch_gemm_split decides): fp32 partial sums [ks][M][N], >= kSplitKBytes when set
     float* splitk_ws = nullptr;
-    _Float16* Khi = nullptr;
-    _Float16* Klo = nullptr;
-    _Float16* Vhi = nullptr;
-    _Float16* Vlo = nullptr;
+    long qkv_stride = 0;  // kEpiQkvScatter: k planes at Chi / Clo + qkv_stride, v planes at + 2 qkv_stride (halves)
     int T = 0;
     // kEpiPosConv (grouped positional conv as a GEMM over the group-major halo layout, see launch_group_major_split):
     // z1 = clip, z2 = group; C = R + GELU(acc + bias) + sin_table[pos(t)], pos = t+2 for t < frames[z1] else 1
