@@ -48,6 +48,29 @@ def disassemble(lib_path):
         return len(objs), "\n".join(text)
 
 
+def scratch_users(lib_path):
+    """-> {kernel symbol: private segment bytes} for every kernel of the library's gfx950 code objects that uses scratch (register
+    spills or dynamically indexed locals), from the code objects' metadata notes."""
+    readelf = os.path.join(LLVM, "llvm-readelf")
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib_path, local)
+        subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=tmp)
+        for f in sorted(f for f in os.listdir(tmp) if "amdgcn" in f and f.endswith("gfx950")):
+            notes = subprocess.run([readelf, "--notes", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s*\.name:\s+(\S+)", line)
+                if m:
+                    name = m.group(1)
+                m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+                if m and name and int(m.group(1)):
+                    out[name] = int(m.group(1))
+    return out
+
+
 def check(lib_path):
     n, text = disassemble(lib_path)
     return n, text.count("v_mfma_"), offenders_in_text(text)

@@ -77,6 +77,20 @@ def test_the_library_that_is_loaded_carries_no_banned_encoding():
     assert mod.offenders_in_text("\tv_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]   // 000000001A2C: D3B04020\n")
 
 
+def test_the_split_precision_kernels_use_no_scratch():
+    """Every instantiation of the default mode's kernels keeps its state in registers: a spill inside the GEMM's k-loop cost 8 % when
+    it happened, and an argument struct that is indexed at run time lands in scratch silently (the q | k | v scatter did,
+    with six plane pointers to choose from, until it addressed its planes by one stride).  Read from the metadata of the code objects
+    in the library that is loaded; the exact-fp32 GEMM's 36 bytes (blocked accumulation) are the one known exception."""
+    lib = os.path.join(ROOT, "loco-asr_amd", "libloco_asr.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    users = check_isa.scratch_users(lib)
+    unexpected = {k: v for k, v in users.items() if "gemm_f32_kernel" not in k}
+    assert not unexpected, unexpected
+    assert all(v <= 64 for v in users.values()), users
+
+
 def test_the_detector_sees_the_form():
     import tempfile
     with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as fh:
