@@ -82,9 +82,13 @@ def test_the_split_precision_kernels_use_no_scratch():
     it happened, and an argument struct that is indexed at run time lands in scratch silently (the q | k | v scatter did,
     with six plane pointers to choose from, until it addressed its planes by one stride).  Read from the metadata of the code objects
     in the library that is loaded; the exact-fp32 GEMM's 36 bytes (blocked accumulation) are the one known exception."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa", os.path.join(CSRC, "check_isa.py"))
+    check_isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(check_isa)
     lib = os.path.join(ROOT, "loco-asr_amd", "libloco_asr.so")
-    if not os.path.exists(lib):
-        pytest.skip("library not built")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(check_isa.LLVM, "llvm-readelf")):
+        pytest.skip("library or llvm-readelf not available")
     users = check_isa.scratch_users(lib)
     unexpected = {k: v for k, v in users.items() if "gemm_f32_kernel" not in k}
     assert not unexpected, unexpected
