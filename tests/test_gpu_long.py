@@ -165,3 +165,24 @@ def test_real_sized_groupnorm_gain_does_not_send_ten_minute_clips_to_fp32(oracle
     assert 50 < amax < 65504, amax
     for lo, hi in ((0, 4), (20000, 20004)):
         assert rel_l2(st["conv_stack"][0, lo:hi], oracle.feature_encoder_window(x[0], sd, lo, hi)) < 1e-5
+
+
+def test_exact_fp32_mode_at_ten_minutes(oracle):
+    """The mode a batch is re-run in when it leaves the fp16 planes' range must itself work at Fisher length: one 10-minute clip on the
+    exact-fp32 kernels (fp32 MFMA GEMMs, the table GEMM, attention_f32 over 469 key tiles), two layers, against the same fp64 row oracle."""
+    m, sd = model(layers=2, precision="f32")
+    enc = m.speecht5.encoder
+    x = torch.from_numpy(la.synth.clip(79, L10))[None]
+    st = {}
+    out = enc(input_values=x.cuda(), output_hidden_states=True, stage_taps=st)
+    torch.cuda.synchronize()
+    assert tuple(out.last_hidden_state.shape) == (1, 29999, 768) and bool(torch.isfinite(out.last_hidden_state).all())
+    ref = oracle.feature_encoder_window(x[0], sd, 29994, 29999)
+    assert rel_l2(st["conv_stack"][0, 29994:29999], ref) < 1e-5
+    ref = oracle.pos_conv_rows(st["feature_projection"][0].cpu(), ROWS, 29999, sd)
+    assert rel_l2(st["prenet"][0, ROWS], ref) < 1e-5
+    pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
+    for layer in (0, 1):
+        ref = oracle.encoder_layer_rows(out.hidden_states[layer][0].cpu(), ROWS, None, sd, f"wrapped_encoder.layers.{layer}.", pe_k)
+        assert rel_l2(out.hidden_states[layer + 1][0, ROWS], ref) < 1e-5
+    enc.precision = "f16x3"
