@@ -186,3 +186,28 @@ def test_exact_fp32_mode_at_ten_minutes(oracle):
         ref = oracle.encoder_layer_rows(out.hidden_states[layer][0].cpu(), ROWS, None, sd, f"wrapped_encoder.layers.{layer}.", pe_k)
         assert rel_l2(out.hidden_states[layer + 1][0, ROWS], ref) < 1e-5
     enc.precision = "f16x3"
+
+
+def test_the_range_fallback_runs_a_ragged_ten_minute_batch(oracle):
+    """A checkpoint whose FFN leaves the fp16 planes' range, on a ragged batch of a 10-minute and a 4-minute clip: the default policy
+    detects it after the f16x3 pass and runs THAT batch again on the exact-fp32 kernels -- masked attention over 469 key tiles
+    included -- with the workspace it was given for the first pass."""
+    layers = 1
+    sd = dict(la.synth.encoder_state_dict(0, layers=layers))
+    for suffix in ("weight", "bias"):
+        k = f"wrapped_encoder.layers.0.feed_forward.intermediate_dense.{suffix}"
+        sd[k] = (sd[k] * np.float32(40000.0)).astype(np.float32)
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({a: torch.from_numpy(v) for a, v in pre.items()},
+                                                         {a: torch.from_numpy(v) for a, v in enc_sd.items()}, layers=layers).cuda()
+    enc = m.speecht5.encoder
+    lens = [L10, 3_840_000]
+    x, msk = la.synth.batch(lens, first_index=95)
+    out = enc(input_values=torch.from_numpy(x).cuda(), attention_mask=torch.from_numpy(msk).cuda(), output_hidden_states=True)
+    torch.cuda.synchronize()
+    assert enc.last_range_fallback and bool(torch.isfinite(out.last_hidden_state).all())
+    nv = la.synth.conv_out_length(lens[1])
+    pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
+    rows = [0, 200, nv - 1, nv, 29998]
+    ref = oracle.encoder_layer_rows(out.hidden_states[0][1].cpu(), rows, nv, sd, "wrapped_encoder.layers.0.", pe_k)
+    assert rel_l2(out.hidden_states[1][1, rows], ref) < 1e-5
