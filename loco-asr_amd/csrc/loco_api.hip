@@ -695,7 +695,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
         if (hidden_states && hidden_states[l] && (rc = run_copy(e, s, hidden_states[l], x0, (size_t)M * kHidden))) return rc;
         const std::string b = we + "layers." + std::to_string(l) + ".";
         const LayerW& lw = e->layers[l];
-        // fused q|k|v projection -> q, k as fp16 hi/lo planes, v transposed per head (the layouts attention_f16x3 reads)
+        // fused q|k|v projection -> q, k and v as fp16 hi/lo planes [M,768] (the layout attention_f16x3 reads; it transposes V itself)
         if ((rc = run_gemm_split(e, c, s, x0hi, x0lo, kHidden, lw.sqkv, kHidden, lw.bqkv, nullptr, 0, nullptr, qshi, qslo, kHidden, (int)M,
                                  kQkv, kHidden, kEpiQkvScatter, 1, 0, 0, 1, 0, 0, &scat, nullptr, nullptr,
                                  slot("attention q|k|v projections", l))))
