@@ -333,7 +333,8 @@ int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const
  * fill the chip): K is cut into slices computed side by side, partial sums (fp32, >= loco_gemm_splitk_bytes()) are added in
  * a fixed order by a second kernel that applies the epilogue.  Larger problems ignore the workspace. */
 size_t loco_gemm_splitk_bytes(void);
-/* diagnostics: re-read the LOCO_GEMM_* A/B knobs (tile form, persistence, ...) from the environment; they are otherwise read once */
+/* diagnostics: re-read the LOCO_GEMM_* A/B knobs (tile form, persistence, ...) and LOCO_ATTN_LONG (0 / 1: force the attention
+ * instantiation without / with the long-sequence rescale skip) from the environment; they are otherwise read once */
 void loco_debug_reload_gemm_knobs(void);
 int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
                               const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc,

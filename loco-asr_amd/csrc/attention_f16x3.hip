@@ -23,6 +23,8 @@
 // scratch = 72.5 KiB, two workgroups per CU.  The loop is software-pipelined INSIDE each wave (QK of tile t+1 against the
 // softmax of tile t, see the main loop): the chip is power-limited here, so what that buys is fewer stalls per joule, not
 // a higher matrix-pipe duty cycle at the nominal clock.
+#include <cstdlib>
+
 #include "loco_kernels.h"
 
 namespace loco {
@@ -629,6 +631,18 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
     }
 }
 
+// A/B and test knob: LOCO_ATTN_LONG=0 / 1 forces the instantiation without / with the long-sequence rescale skip (read once, and again
+// on loco_debug_reload_gemm_knobs); unset = chosen by T.
+static int read_attn_long_knob() {
+    const char* v = getenv("LOCO_ATTN_LONG");
+    return v ? (atoi(v) != 0) : -1;
+}
+static int& attn_long_knob() {
+    static int k = read_attn_long_knob();
+    return k;
+}
+void reload_attention_knobs() { attn_long_knob() = read_attn_long_knob(); }
+
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
                                   const _Float16* vhi, const _Float16* vlo, const float* qp, const int32_t* frames,
                                   _Float16* ctx_hi, _Float16* ctx_lo, float* ctx, int B, int T, hipStream_t s,
@@ -640,7 +654,8 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
     dim3 grid((unsigned)nblk);
     float* qpw = const_cast<float*>(qp);  // written only in the pe_hi != nullptr form (the table is then an output / scratch of this launch)
     if ((pe_hi == nullptr) != (pe_lo == nullptr)) return hipErrorInvalidValue;
-    const bool long_seq = T >= 8192;
+    const int forced = attn_long_knob();
+    const bool long_seq = forced < 0 ? T >= 8192 : forced != 0;
 #define AX_LAUNCH1(SPLIT_, TABLE_, LONG_)                                                                                              \
     hipLaunchKernelGGL((attention_f16x3_kernel<SPLIT_, TABLE_, LONG_>), grid, dim3(256), 0, s, qhi, qlo, khi, klo, vhi, vlo, qpw, frames, ctx_hi, \
                        ctx_lo, ctx, T, nqb, pe_hi, pe_lo, pe_scale)

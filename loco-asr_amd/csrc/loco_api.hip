@@ -1580,7 +1580,10 @@ int loco_op_conv_gemm_f16x3(const void* Ahi, const void* Alo, int64_t lda, const
 
 size_t loco_gemm_splitk_bytes(void) { return kSplitKBytes; }
 
-void loco_debug_reload_gemm_knobs(void) { reload_gemm_knobs(); }
+void loco_debug_reload_gemm_knobs(void) {
+    reload_gemm_knobs();
+    reload_attention_knobs();
+}
 
 int loco_op_gemm_f16x3_splitk(const void* Ahi, const void* Alo, int64_t lda, const void* Whi, const void* Wlo, int64_t ldw,
                               const float* bias, const float* R, int64_t ldr, float* C, void* Chi, void* Clo, int64_t ldc, int32_t M,

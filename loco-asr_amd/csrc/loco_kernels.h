@@ -112,6 +112,7 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
 // into `qp`, which is then scratch of the launch ([B,12,T,320] fp32) instead of an input.
 hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s);
 void reload_gemm_knobs();  // re-read the LOCO_GEMM_* A/B knobs from the environment (gemm_f16x3.hip)
+void reload_attention_knobs();  // ... and LOCO_ATTN_LONG (attention_f16x3.hip)
 // hi/lo planes of x * scale (scale a power of two)
 hipError_t launch_split_f16(const float* x, void* hi, void* lo, long n, hipStream_t s, float scale = 1.0f);
 // max |x| over n elements -> *out (one float, device); out must be zeroed by the caller
