@@ -483,9 +483,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         kf[0][2] = AX_KF(kb, 1, 0, 0); kf[0][3] = AX_KF(kb, 1, 0, 1);                                                  \
         const f32x2 al2 = {alpha, alpha}, k2 = {kLog2e, kLog2e}, d2 = {dsh, dsh};                                      \
         f32x2 ps2 = {0.f, 0.f};                                                                                        \
-        /* LONG_SEQ (T >= 8 192, chosen by the launcher): once the running maximum has settled, alpha is exactly 1 in every lane for    \
-           most tiles and the 32 multiplications are skipped -- bit-identical, -1.2 % at T = 29 999.  Short sequences take the         \
-           instantiation without the test: at T = 1 499 it cost 2 % (even untaken, the branch un-pins the schedule of the body). */     \
+        /* LONG_SEQ (T >= 4 096, chosen by the launcher): once the running maximum has settled, alpha is exactly 1 in every lane for    \
+           most tiles and the 32 multiplications are skipped -- bit-identical; interleaved A/B (tools/attn_long_ab.py): +0.0 % at       \
+           T = 1 499, -0.3 % at 4 000, -0.8 % at 8 192, -1.6 % at 29 999.  Short sequences keep the instantiation without the test. */   \
         if (!LONG_SEQ || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {                                            \
             _Pragma("unroll") for (int e = 0; e < 16; e += 2) {                                                        \
                 f32x2 a_ = {o0[e], o0[e + 1]}, c_ = {o1[e], o1[e + 1]};                                                \
@@ -655,7 +655,7 @@ hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, cons
     float* qpw = const_cast<float*>(qp);  // written only in the pe_hi != nullptr form (the table is then an output / scratch of this launch)
     if ((pe_hi == nullptr) != (pe_lo == nullptr)) return hipErrorInvalidValue;
     const int forced = attn_long_knob();
-    const bool long_seq = forced < 0 ? T >= 8192 : forced != 0;
+    const bool long_seq = forced < 0 ? T >= 4096 : forced != 0;
 #define AX_LAUNCH1(SPLIT_, TABLE_, LONG_)                                                                                              \
     hipLaunchKernelGGL((attention_f16x3_kernel<SPLIT_, TABLE_, LONG_>), grid, dim3(256), 0, s, qhi, qlo, khi, klo, vhi, vlo, qpw, frames, ctx_hi, \
                        ctx_lo, ctx, T, nqb, pe_hi, pe_lo, pe_scale)

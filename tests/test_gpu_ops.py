@@ -570,7 +570,7 @@ def test_gemm_f16x3_split_k(M, N, K, epi, out_split):
 
 @pytest.mark.parametrize("B,T,frames", [(2, 700, [700, 333]), (1, 3001, None)])
 def test_attention_f16x3_long_sequence_instantiation_is_bit_identical(B, T, frames):
-    """Sequences of T >= 8 192 take an instantiation that skips the O rescale of a tile when alpha is exactly 1 in every lane of the
+    """Sequences of T >= 4 096 take an instantiation that skips the O rescale of a tile when alpha is exactly 1 in every lane of the
     wave (attention_f16x3.hip).  Multiplying by 1 changes nothing, so forcing either instantiation on the same input (LOCO_ATTN_LONG,
     re-read on loco_debug_reload_gemm_knobs) must give the same bits; the long tests check the long one against the oracle."""
     import os
