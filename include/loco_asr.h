@@ -269,6 +269,10 @@ typedef struct loco_kernel_stat {
 } loco_kernel_stat;
 
 int loco_set_profiling(loco_encoder* enc, int on);
+/* Bracket only the launches of ONE bucket (a loco_kernel_stat name, e.g. "gemm_f16x3"); NULL or "" = all of them again.  Two event
+ * records per launch cost ~1 ms of a 52 ms forward when every launch carries them: bench.py times its steps with events on the
+ * dominant bucket only and takes the per-kernel table from its warm-up steps. */
+int loco_set_profiling_filter(loco_encoder* enc, const char* bucket);
 int loco_profile_reset(loco_encoder* enc);
 int loco_profile_read(loco_encoder* enc, loco_kernel_stat* stats, int max_stats); /* returns count */
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "loco_set_streams": (C.c_int, [_vp, C.c_int]),
     "loco_set_taps": (C.c_int, [_vp, _vp, _vp, _vp]),
     "loco_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "loco_set_profiling_filter": (C.c_int, [_vp, C.c_char_p]),
     "loco_profile_reset": (C.c_int, [_vp]),
     "loco_profile_read": (C.c_int, [_vp, C.POINTER(KernelStat), C.c_int]),
     "loco_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f, _vp]),

@@ -156,6 +156,7 @@ struct loco_encoder {
     std::string range_static;     // non-empty: a weight-determined plane tensor (a LayerNorm output) leaves the range
     // profiling
     bool profiling = false;
+    int profile_only = -1;  // >= 0: only launches of this kernel bucket are bracketed (loco_set_profiling_filter)
     std::vector<ProfRec> recs;
     size_t recs_used = 0;
     loco_kernel_stat stats[K_COUNT];
@@ -292,7 +293,7 @@ struct Bracket {
     hipStream_t s;
     ProfRec* rec = nullptr;
     Bracket(loco_encoder* enc, hipStream_t st, int kid, double flops, double bytes) : e(enc), s(st) {
-        if (!e->profiling) return;
+        if (!e->profiling || (e->profile_only >= 0 && e->profile_only != kid)) return;
         if (e->recs_used == e->recs.size()) {
             ProfRec r{};
             if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -1422,6 +1423,20 @@ int loco_set_profiling(loco_encoder* e, int on) {
     if (!e) return fail(LOCO_E_INVALID, "null encoder");
     e->profiling = on != 0;
     return LOCO_OK;
+}
+
+int loco_set_profiling_filter(loco_encoder* e, const char* bucket) {
+    if (!e) return fail(LOCO_E_INVALID, "null encoder");
+    if (!bucket || !*bucket) {
+        e->profile_only = -1;
+        return LOCO_OK;
+    }
+    for (int i = 0; i < K_COUNT; ++i)
+        if (!strcmp(bucket, kKernelNames[i])) {
+            e->profile_only = i;
+            return LOCO_OK;
+        }
+    return fail(LOCO_E_INVALID, "loco_set_profiling_filter: no kernel bucket named '%s'", bucket);
 }
 
 static int drain_records(loco_encoder* e) {

@@ -322,6 +322,11 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         self._ensure_handle(self._device())
         _lib.check(self._lib.loco_set_profiling(self._handle, int(on)))
 
+    def set_profiling_filter(self, bucket: Optional[str]):
+        """Bracket only the launches of one kernel bucket (a name profile_read returns); None = all."""
+        self._ensure_handle(self._device())
+        _lib.check(self._lib.loco_set_profiling_filter(self._handle, (bucket or "").encode()))
+
     def profile_reset(self):
         _lib.check(self._lib.loco_profile_reset(self._handle))
 
