@@ -18,12 +18,12 @@ Extra objects on the line:
                 30 s x 32, attention at 10 min x 4; picked from the warm-up steps, whose every launch is bracketed):
                 algorithmic FLOPs / its summed launch time, measured live with HIP events on the launch stream
                 over the timed region -- in which only THIS bucket's launches carry events (two records around each of
-                ~100 launches cost ~1 ms of a 52 ms step); peak = the dense MFMA
+                ~100 launches cost ~2 ms of a 52 ms step); peak = the dense MFMA
                 rate of the instruction it issues (fp16: 2.5 PFLOP/s; fp32: 157.3 TFLOP/s; MI355X_MICROARCH.md);
                 for f16x3 the 3-MFMAs-per-product issue rate is reported beside the algorithmic fraction;
                 traffic = PMC HBM bytes when profiles/ holds them, else null.
-  kernels       per-bucket launches / ms / rate per step, from the W warm-up steps (every launch bracketed); with --warmup 0 the
-                timed steps themselves are bracketed launch by launch, as before.
+  kernels       per-bucket launches / ms / rate per step, from up to 5 further steps after the timed region (every launch
+                bracketed); with --warmup 0 the timed steps themselves are bracketed launch by launch, as before.
   alt_precision the other precision mode measured for 3 steps in the same process.
   cpu_baseline  the CPU oracle (oracle/speecht5_oracle.py, torch fp32, all host cores) timed on a bounded
                 sample of the same workload (8 clips of 30 s: 1 warm-up + 3 timed passes, median) on rank 0 at
@@ -275,6 +275,16 @@ def main():
         raise SystemExit("bench.py: the synthetic batch left the f16x3 activation range and was re-run in fp32 -- not a valid f16x3 measurement")
     stats = enc.profile_read()
     enc.set_profiling_filter(None)
+    # the per-kernel table: a few more steps, every launch bracketed, on the warm chip (the warm-up steps include the first, cold one)
+    table_stats, table_steps = [], 0
+    if dominant:
+        table_steps = max(1, min(args.steps, 5))
+        enc.profile_reset()
+        for _ in range(table_steps):
+            step()
+        gatherer.finish()
+        torch.cuda.synchronize()
+        table_stats = enc.profile_read()
     enc.set_profiling(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -287,7 +297,7 @@ def main():
     result = None
     if rank == 0:
         by = {s["name"]: s for s in stats}
-        table, table_steps = (warm_stats, args.warmup) if dominant else (stats, args.steps)
+        table, table_steps = (table_stats, table_steps) if dominant else (stats, args.steps)
         kernels = {s["name"]: {"launches_per_step": s["launches"] / table_steps, "ms_per_step": s["ms"] / table_steps,
                                "tflops": (s["flops"] / (s["ms"] * 1e-3) / 1e12) if s["ms"] > 0 and s["flops"] else None,
                                "gbps": (s["bytes"] / (s["ms"] * 1e-3) / 1e9) if s["ms"] > 0 and s["bytes"] else None}
@@ -295,9 +305,9 @@ def main():
         wkey = f"{args.clip_seconds:g}sx{B}" if args.clip_seconds < 60 else f"{args.clip_seconds / 60:g}minx{B}"
         roofline = make_roofline(by, args.precision, args.steps, wkey)
         if roofline and dominant:  # the share among ALL kernels comes from the fully bracketed warm-up steps
-            roofline["share_of_kernel_time"] = round(next(s_["ms"] for s_ in warm_stats if s_["name"] == dominant) / sum(s_["ms"] for s_ in warm_stats), 3)
+            roofline["share_of_kernel_time"] = round(next(s_["ms"] for s_ in table if s_["name"] == dominant) / sum(s_["ms"] for s_ in table), 3)
             roofline["events"] = (f"timed region: hipEvents around the {roofline['launches_per_step']:g} launches per step of this bucket only; "
-                                  f"`kernels` and share_of_kernel_time: the {args.warmup} warm-up steps, every launch bracketed")
+                                  f"`kernels` and share_of_kernel_time: {table_steps} further steps after it, every launch bracketed")
         whole = flops_per_clip(T) * B * world * args.steps / elapsed / 1e12
         result = {
             "metric": "audio frames/sec SpeechT5-base encoder, 30s×bs32 @1/2/4/8 GPU; embed L2 vs HF",
