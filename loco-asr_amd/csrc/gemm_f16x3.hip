@@ -619,6 +619,135 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 #undef VMCNT_LGKM0
 #undef DMA16
 
+// ---------------------------------------------------------------------------------------------------------------
+// The grouped positional conv with its A operand RESIDENT in LDS.  As a GEMM over the group-major halo layout (A row t = the
+// contiguous run of 128 taps x 48 channels starting at input row t, lda = 48, K = 6144) every k-tile of every output row is a
+// different 64-byte window of the SAME 640 input rows of a 512-frame tile: the generic kernel DMA's 12.6 MB through L2 -> LDS per
+// tile to multiply 123 KB of unique data, 64 KiB per k-tile against 576 MFMA cycles per wave -- exactly the CU's LDS-DMA rate, so
+// that kernel is bound by it (285 TFLOP/s against ~400 for the other GEMMs).  Here the 640 rows x 48 channels (hi + lo planes) are
+// loaded ONCE -- rows padded to 56 halves (112 B = 7 x 16 B: 16 consecutive rows then start in 16 different 16-byte bank groups;
+// the natural 96 B would put rows r and r + 8 on the same ones) -- and a fragment is read where it lies: chunk g8 = 4 kt + q4 of a
+// row's k axis is tap g8 / 6, channels 8 (g8 % 6) .. + 7, i.e. LDS row (frame + tap), one 16-byte piece.  Only the weights stream
+// (6 KiB per k-tile, three ring slots).  Same MFMA sequence per output element as the generic kernel (k-tiles ascending, the
+// three terms in its order): bit-identical results (tools/bit_compare.py).
+constexpr int PCR_BM = 512, PCR_ROWS = PCR_BM + kPosK, PCR_S = 56;   // frames per tile, input rows per tile, padded row pitch (halves)
+constexpr int PCR_APL = PCR_ROWS * PCR_S;                            // halves per A plane
+constexpr int PCR_WPL = kPosCg * SBK;                                // halves per W plane of one k-tile
+constexpr int PCR_WST = 3;                                           // W ring slots
+static_assert((2 * PCR_APL + PCR_WST * 2 * PCR_WPL) * 2 <= 160 * 1024, "LDS");
+#define PCR_DMA16(base_, voff_, ldsb_) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+
+template <int TERMS>
+__global__ __launch_bounds__(512, 2) void pos_conv_resident_kernel(GemmSplitArgs p) {
+    __shared__ __attribute__((aligned(16))) _Float16 lds[2 * PCR_APL + PCR_WST * 2 * PCR_WPL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int t0 = blockIdx.x * PCR_BM, g = blockIdx.y, b = blockIdx.z;
+    const unsigned lds0 = (unsigned)(unsigned long)(lptr_t)lds;
+    const int rows_total = p.M + kPosK;  // rows of the (clip, group) block: frames + the 64-frame halo on both sides
+    const char* const abase_h = reinterpret_cast<const char*>(p.Ahi + b * p.sA1 + g * p.sA2);
+    const char* const abase_l = reinterpret_cast<const char*>(p.Alo + b * p.sA1 + g * p.sA2);
+    const char* const wbase_h = reinterpret_cast<const char*>(p.Whi + g * p.sW2);
+    const char* const wbase_l = reinterpret_cast<const char*>(p.Wlo + g * p.sW2);
+
+    // ---- the resident A block: piece P of a plane = LDS bytes 16 P .. 16 P + 15 = row P / 7, piece P % 7 (the seventh is padding and
+    //      re-reads the sixth); one instruction moves 64 pieces; rows past the block's end re-read its last row (they feed frames >= T)
+    constexpr int kPiecesPerPlane = PCR_ROWS * 7, kInstrPerPlane = (kPiecesPerPlane + 63) / 64;
+    for (int n = wave; n < 2 * kInstrPerPlane; n += 8) {
+        const int pl = n >= kInstrPerPlane, ni = pl ? n - kInstrPerPlane : n;
+        int P = 64 * ni + lane;
+        P = P < kPiecesPerPlane ? P : kPiecesPerPlane - 1;
+        const int row = P / 7, c = P - 7 * row;
+        int grow = t0 + row;
+        grow = grow < rows_total ? grow : rows_total - 1;
+        const unsigned vo = (unsigned)grow * (2u * kPosCg) + 16u * (unsigned)(c < 6 ? c : 5);
+        const unsigned d = lds0 + 2u * (unsigned)(pl * PCR_APL) + 1024u * (unsigned)ni;
+        PCR_DMA16(pl ? abase_l : abase_h, vo, d);
+    }
+    // ---- W k-tile kt -> ring slot: waves 0-5 move one 16-row piece each (plane = wave / 3); lane -> row lane / 4, stored piece lane % 4
+    //      holding source piece (lane % 4) ^ swz(row), swz = 3 * ((row >> 2) & 1) -- the generic kernel's conflict-free W image
+    const int wrow = 16 * (wave % 3) + (lane >> 2), wpos = lane & 3;
+    const unsigned wvo = (unsigned)wrow * (unsigned)(2 * p.ldw) + 16u * (unsigned)(wpos ^ (3 * ((wrow >> 2) & 1)));
+    const int nk = p.K / SBK;
+#define PCR_DMA_W(kt_, slot_)                                                                                                   \
+    if (wave < 6) {                                                                                                             \
+        const int kk_ = (kt_) < nk ? (kt_) : nk - 1;                                                                            \
+        const unsigned d_ = lds0 + 2u * (unsigned)(2 * PCR_APL + (slot_) * 2 * PCR_WPL + (wave / 3) * PCR_WPL + 16 * (wave % 3) * SBK); \
+        PCR_DMA16((wave >= 3 ? wbase_l : wbase_h) + (long)kk_ * (2 * SBK), wvo, d_);                                             \
+    }
+    PCR_DMA_W(0, 0)
+    PCR_DMA_W(1, 1)
+
+    // fragment addresses (halves).  A: row-group i of this wave = frames 64 wave + 16 i + r16; chunk g8 = 4 kt + q4 -> tap g8 / 6,
+    // channel 8 (g8 % 6): aoff walks it (32 halves per k-tile, 8 more whenever the chunk enters the next tap: the row padding).
+    int c8 = q4 % 6, tap = q4 / 6;  // q4 < 4: tap 0
+    int aoff = (64 * wave + r16 + tap) * PCR_S + 8 * c8;
+    const int woff = r16 * SBK + 8 * (q4 ^ (3 * ((r16 >> 2) & 1)));
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // W(kt) has landed (its DMA was issued two k-tiles ago; W(kt + 1) may still be in flight: 1 instruction per wave), and -- first
+        // iteration -- so has the resident block; every wave has finished reading the slot W(kt + 2) is about to overwrite
+        if (kt == 0 && wave >= 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // waves 6, 7 move no weights: their last A piece
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int s2 = slot + 2 >= PCR_WST ? slot + 2 - PCR_WST : slot + 2;
+            PCR_DMA_W(kt + 2, s2)
+        }
+        const _Float16* wb = lds + 2 * PCR_APL + slot * 2 * PCR_WPL;
+        h8 wh[3], wl[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            wh[j] = *reinterpret_cast<const h8*>(wb + 16 * j * SBK + woff);
+            if (TERMS == 3) wl[j] = *reinterpret_cast<const h8*>(wb + PCR_WPL + 16 * j * SBK + woff);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h8 ah = *reinterpret_cast<const h8*>(lds + aoff + 16 * i * PCR_S);
+            const h8 al = *reinterpret_cast<const h8*>(lds + PCR_APL + aoff + 16 * i * PCR_S);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (TERMS == 3) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], al, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah, acc[i][j], 0, 0, 0);
+            }
+        }
+        c8 += 4;
+        const bool wrap = c8 >= 6;
+        c8 -= wrap ? 6 : 0;
+        aoff += 32 + (wrap ? PCR_S - kPosCg : 0);
+        slot = slot + 1 == PCR_WST ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the surplus W DMAs of the last two k-tiles: none may land after the LDS is given away
+#undef PCR_DMA_W
+
+    // ---- epilogue: acc[i][j][e] = C[frame t0 + 64 wave + 16 i + r16][output 16 j + 4 q4 + e], the generic kernel's kEpiPosConv store
+    const long coff = b * p.sC1 + g * p.sC2;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = t0 + 64 * wave + 16 * i + r16;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = 16 * j + 4 * q4;
+            f32x4 v = acc[i][j] * p.out_scale;
+            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + g * p.sBias2 + n);
+            split_gemm_store<kEpiPosConv, false>(p, v, coff, m, n, amax, b, g);
+        }
+    }
+}
+#undef PCR_DMA16
+
 // Sum of the ks partial results of the split-K path (fixed order) + bias, then the shared epilogue.  Thread = 4 columns; a grid of
 // at most 1024 blocks strides over the output (few, fat workgroups: one range atomic each, range_commit_block).
 template <int EPI, bool OUT_SPLIT>
@@ -699,7 +828,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_posconv_kernel(GemmSplitArg
 // per forward and possibly on several host threads -- and again only when a tool asks for it (loco_debug_reload_gemm_knobs).
 struct GemmKnobs {
     int tile = 0, narrow = 0;
-    bool nopersist = false, nocolgroup = false, no192 = false, nosplitk = false;
+    bool nopersist = false, nocolgroup = false, no192 = false, nosplitk = false, posconv_generic = false;
 };
 static GemmKnobs read_gemm_knobs() {
     GemmKnobs k;
@@ -709,6 +838,7 @@ static GemmKnobs read_gemm_knobs() {
     k.nopersist = getenv("LOCO_GEMM_NOPERSIST") != nullptr;
     k.nocolgroup = getenv("LOCO_GEMM_NOCOLGROUP") != nullptr;
     k.no192 = getenv("LOCO_GEMM_NO192") != nullptr;
+    k.posconv_generic = getenv("LOCO_POSCONV_GENERIC") != nullptr;  // A/B: the positional conv on the generic GEMM kernel (A re-fetched per k-tile)
     k.nosplitk = getenv("LOCO_GEMM_NOSPLITK") != nullptr;  // A/B: small problems as ONE launch each (no partial sums, no reduction kernel)
     return k;
 }
@@ -803,6 +933,15 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
                 hipLaunchKernelGGL(splitk_reduce_posconv_kernel, dim3(blocks), dim3(256), 0, s, a, ks);
                 return hipGetLastError();
             }
+        }
+        // the layout the resident-A kernel is written for (launch_group_major_split): lda = 48, K = 128 taps x 48, z1 = clip, z2 = group
+        const bool resident = !gemm_knobs().posconv_generic && a.z1_inner == 1 && a.lda == kPosCg && a.K == kPosK * kPosCg && a.nb2 == kPosGroups &&
+                              a.nb1 <= 65535 && a.sA2 == (long)(a.M + kPosK) * kPosCg && ((2 * a.ldw) & 15) == 0;
+        if (resident) {
+            const dim3 grid((unsigned)((a.M + PCR_BM - 1) / PCR_BM), kPosGroups, (unsigned)a.nb1);
+            if (a.terms == 2) hipLaunchKernelGGL(pos_conv_resident_kernel<2>, grid, dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(pos_conv_resident_kernel<3>, grid, dim3(512), 0, s, a);
+            return hipGetLastError();
         }
         if (a.terms == 2)
             hipLaunchKernelGGL((gemm_f16x3_dma_kernel<kEpiPosConv, false, 8, 1, 2, 2, 3, 0, 2>), dim3((unsigned)nb), dim3(512), 0, s, a, tm, 1,
