@@ -18,7 +18,7 @@ rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
 worst = 0.0
 for case in range(N):
     B = rng.choice([1, 1, 2, 2, 3, 4, 5, 7, 8, 9, 16, 24])
-    longest = rng.choice([400, 401, 719, 720, 1000, 8000, 16000, 40000, 80000, 81234, 160000, 163840, 200001, 480000, 700000])
+    longest = rng.choice([400, 401, 719, 720, 1000, 8000, 16000, 40000, 80000, 81234, 160000, 163840, 200001, 480000, 700000, 1400000, 2000123])
     if B * longest > 9_000_000:
         B = max(1, 9_000_000 // longest)
     lens = [longest] + [rng.randint(400, longest) for _ in range(B - 1)]
