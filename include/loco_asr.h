@@ -173,6 +173,39 @@ int loco_forward_async(loco_encoder* enc, int precision, const float* wav, const
                        float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes,
                        void* stream, void* status);
 int loco_status_check(const void* status, char* buf, size_t buflen);
+
+/* ---- packed forward: G reference batches in ONE launch sequence ---------------------------------------------------------------
+ * The reference's loop encodes batch after batch of two utterances (batch_size = 2, shuffle=False,
+ * /root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:51-68 collate_fn + DataLoader, :108 the forward).  A pair
+ * of 2-6 s clips is a few hundred frames; every GEMM of it is a handful of tiles.  Batch composition is part of the function --
+ * GroupNorm statistics run over the padded time axis of the batch (HF modeling_speecht5.py:275-279), the positional conv sees
+ * zeros where the batch ends (:389-397) -- so the batches cannot simply be merged.  What CAN be merged is the launch sequence:
+ * loco_forward_packed runs the clips of any number of reference batches as one [B, L] problem in which every clip carries the
+ * padded length of ITS OWN batch,
+ *   pad_len  int64 [B], HOST memory, read before the call returns: samples of clip b's own reference batch after padding (the
+ *            longest clip of that batch), 400 <= pad_len[b] <= L.  L = the largest of them (or more).
+ *   wav      f32 [B, L] device: clip b in wav[b, 0 .. pad_len[b]) exactly as its own batch would hold it (its samples, then the
+ *            zeros of padding="longest"); what lies beyond pad_len[b] is never used
+ *   attention_mask  i32 [B, L] device or NULL: as in loco_forward for the first pad_len[b] entries of row b; entries beyond MUST be
+ *            0 (the valid-frame count is the row sum).  NULL = every sample below pad_len[b] is present.
+ * and per clip b, with T_b = loco_output_frames(pad_len[b]) and T = loco_output_frames(L):
+ *   - GroupNorm moments of conv layer 0 over the conv frames of pad_len[b] samples -- the zero tail of its own batch counts,
+ *     nothing beyond (the same fp64 partial sums in the same order as a forward of that batch alone);
+ *   - the positional conv reads zeros from frame T_b on; sinusoid positions 2.. for valid frames, the pad row from there on;
+ *   - keys >= its valid frames are masked in attention (so are all keys >= T_b);
+ *   - out[b, t, :] for t < T_b is what loco_forward gives for clip b inside its own batch, including that batch's padded frames
+ *     (the reference pickles them); rows T_b <= t < T are unspecified (finite).  out_frames[b] = valid frames, as loco_forward.
+ * Every other operation of the path is row-wise (GEMM rows, LayerNorm) and runs over all B * T rows at once.  A pack therefore
+ * differs from the one-batch forwards it replaces by the fp32 SUMMATION ORDER OF THE GEMMS ONLY (small problems cut K into
+ * slices, loco_set_precision above): <= 5e-6 relative L2, every other step is the same arithmetic in the same order.
+ * Any set of reference batches may share a pack (sorting batches by length before packing minimises the rows T_b..T).
+ * status / precision / workspace / concurrency exactly as loco_forward_async (loco_workspace_bytes(enc, B, L) bytes; the status
+ * block also stages the per-clip lengths: it must stay untouched -- and should be pinned -- until `stream` has completed the
+ * forward).  B <= loco_max_pack_clips(). */
+int loco_max_pack_clips(void);
+int loco_forward_packed(loco_encoder* enc, int precision, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
+                        const int64_t* pad_len, float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
+                        size_t workspace_bytes, void* stream, void* status);
 int loco_status_range(const void* status, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen);
 
 /* ---- sample-rate conversion to 16 kHz ("next" row f-4) ---------------------------------------------------------------------

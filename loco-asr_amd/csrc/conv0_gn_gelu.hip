@@ -25,10 +25,13 @@ size_t conv0_scratch_bytes(int B) {
 }
 
 __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restrict__ wav, long L, long T0,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, const int32_t* __restrict__ t0_clip) {
     __shared__ double red[4][kConv0Moments];
     const int b = blockIdx.y, part = blockIdx.x;
     const float* x = wav + (long)b * L;
+    // packed forward (loco_forward_packed): the statistics of clip b run over the conv frames of ITS OWN reference batch's padded
+    // length, cut into the same kConv0Parts pieces as a forward of that batch alone would cut them -- the same fp64 sums, bit for bit
+    if (t0_clip) T0 = t0_clip[b];
     const long per = (T0 + kConv0Parts - 1) / kConv0Parts;
     const long t_begin = part * per, t_end = (t_begin + per < T0) ? t_begin + per : T0;
     double acc[kConv0Moments];
@@ -63,9 +66,10 @@ __global__ __launch_bounds__(256) void conv0_moments_kernel(const float* __restr
 __global__ __launch_bounds__(512) void conv0_gn_coeffs_kernel(const double* __restrict__ partial, double* __restrict__ total,
                                                               const float* __restrict__ w, const float* __restrict__ gn_w,
                                                               long T0, float eps, float* __restrict__ mean_out,
-                                                              float* __restrict__ scale_out) {
+                                                              float* __restrict__ scale_out, const int32_t* __restrict__ t0_clip) {
     __shared__ double m[kConv0Moments];
     const int b = blockIdx.x;
+    if (t0_clip) T0 = t0_clip[b];
     if (threadIdx.x < kConv0Moments) {
         double s = 0.0;
         for (int p = 0; p < kConv0Parts; ++p) s += partial[((long)b * kConv0Parts + p) * kConv0Moments + threadIdx.x];
@@ -106,7 +110,8 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
                                                           const float* __restrict__ w, const float* __restrict__ gn_b,
                                                           const float* __restrict__ mean, const float* __restrict__ scale,
                                                           float* __restrict__ out, _Float16* __restrict__ out_hi,
-                                                          _Float16* __restrict__ out_lo, float* __restrict__ range_slot) {
+                                                          _Float16* __restrict__ out_lo, float* __restrict__ range_slot,
+                                                          const int32_t* __restrict__ t0_clip) {
     __shared__ float xs[kFramesPerBlock * 5 + 8];
     const unsigned range_seen = SPLIT ? range_peek(range_slot) : 0u;  // read early: the load's latency hides under the taps
     float amax = 0.f;
@@ -130,6 +135,10 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     __syncthreads();
 
     const long obase = ((long)b * T0 + t0) * kConvDim + c0;
+    // packed forward: frames at and beyond the clip's own conv length do not exist in its reference batch; they are written as
+    // zeros (the bias-free conv layers behind keep them zero), never read by a frame that does exist
+    long left = t0_clip ? (long)t0_clip[b] - t0 : (long)nt;
+    const int nreal = (int)(left < 0 ? 0 : (left < nt ? left : nt));
     for (int t = 0; t < nt; ++t) {
         float y0 = 0.f, y1 = 0.f;
 #pragma unroll
@@ -145,7 +154,7 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
         // (`v_pk_fma_f32 v[32:33], v[4:5], v[32:33], v[42:43] op_sel:[0,1,0]`); no other kernel of this library contains that
         // form (tests/test_isa_patterns.py keeps it that way).
         const f32x2_t g_ = gelu_erf2(f32x2_t{fmaf(y0 - mu0, sc0, be0), fmaf(y1 - mu1, sc1, be1)});
-        float r0 = g_.x, r1 = g_.y;
+        float r0 = t < nreal ? g_.x : 0.f, r1 = t < nreal ? g_.y : 0.f;
         if (SPLIT) {  // fp16 hi/lo planes: the A operand of the split-precision conv1 GEMM
             asm volatile("" : "+v"(r0), "+v"(r1));
             amax = fmaxf(amax, fmaxf(fabsf(r0), fabsf(r1)));
@@ -164,22 +173,23 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
 }
 
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
-                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi, void* out_lo, float* range_slot) {
+                                float* out, void* scratch, float eps, hipStream_t s, void* out_hi, void* out_lo, float* range_slot,
+                                const int32_t* t0_clip) {
     const long T0 = conv_out_len(L, 10, 5);
     if (B <= 0 || T0 <= 0) return hipErrorInvalidValue;
     double* partial = reinterpret_cast<double*>(scratch);
     double* total = partial + (size_t)B * kConv0Parts * kConv0Moments;
     float* mean = reinterpret_cast<float*>(total + (size_t)B * kConv0Moments);
     float* scale = mean + (size_t)B * kConvDim;
-    hipLaunchKernelGGL(conv0_moments_kernel, dim3(kConv0Parts, B), dim3(256), 0, s, wav, L, T0, partial);
-    hipLaunchKernelGGL(conv0_gn_coeffs_kernel, dim3(B), dim3(512), 0, s, partial, total, w, gn_w, T0, eps, mean, scale);
+    hipLaunchKernelGGL(conv0_moments_kernel, dim3(kConv0Parts, B), dim3(256), 0, s, wav, L, T0, partial, t0_clip);
+    hipLaunchKernelGGL(conv0_gn_coeffs_kernel, dim3(B), dim3(512), 0, s, partial, total, w, gn_w, T0, eps, mean, scale, t0_clip);
     const unsigned nblk = (unsigned)((T0 + kFramesPerBlock - 1) / kFramesPerBlock);
     if (out_hi)
         hipLaunchKernelGGL(conv0_apply_kernel<true>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
-                           (_Float16*)out_hi, (_Float16*)out_lo, range_slot);
+                           (_Float16*)out_hi, (_Float16*)out_lo, range_slot, t0_clip);
     else
         hipLaunchKernelGGL(conv0_apply_kernel<false>, dim3(nblk, B), dim3(256), 0, s, wav, L, T0, w, gn_b, mean, scale, out,
-                           (_Float16*)nullptr, (_Float16*)nullptr, (float*)nullptr);
+                           (_Float16*)nullptr, (_Float16*)nullptr, (float*)nullptr, t0_clip);
     return hipGetLastError();
 }
 

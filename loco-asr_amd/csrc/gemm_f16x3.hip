@@ -1071,7 +1071,7 @@ __global__ void split_f16_kernel(const float* __restrict__ x, _Float16* __restri
 
 // x [B,T,768] -> group-major hi/lo planes [B][16][T+128][48] with 64 zero frames of halo on both sides
 __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi, _Float16* __restrict__ lo, int T,
-                                         long total4, float* __restrict__ range_slot) {
+                                         long total4, float* __restrict__ range_slot, const int32_t* __restrict__ rows_clip) {
     const int rows = T + kPosK;
     float amax = 0.f;
     const unsigned seen = range_peek(range_slot);
@@ -1084,7 +1084,7 @@ __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* 
         const int b = (int)(rest / kPosGroups);
         const int t = row - kPosK / 2;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < T) v = *reinterpret_cast<const f32x4*>(x + ((long)b * T + t) * kHidden + g * kPosCg + 4 * c4);
+        if (t >= 0 && t < (rows_clip ? rows_clip[b] : T)) v = *reinterpret_cast<const f32x4*>(x + ((long)b * T + t) * kHidden + g * kPosCg + 4 * c4);
         h4 a, c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1098,10 +1098,11 @@ __global__ void group_major_split_kernel(const float* __restrict__ x, _Float16* 
     range_commit_block(range_slot, amax, seen);
 }
 
-hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot) {
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot,
+                                    const int32_t* rows_clip) {
     if (B <= 0 || T <= 0) return hipErrorInvalidValue;
     const long total4 = (long)B * kPosGroups * (T + kPosK) * (kPosCg / 4);
-    hipLaunchKernelGGL(group_major_split_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, T, total4, range_slot);
+    hipLaunchKernelGGL(group_major_split_kernel, dim3(2048), dim3(256), 0, s, x, (_Float16*)hi, (_Float16*)lo, T, total4, range_slot, rows_clip);
     return hipGetLastError();
 }
 

@@ -87,6 +87,7 @@ struct ProfRec {
 // handle's own pinned block for loco_forward.  The host part is filled while the forward is enqueued; `words` is the target of the
 // device-to-host copy that follows the forward on its stream.
 constexpr uint32_t kStatusMagic = 0x53434f4cu;  // "LOCS"
+constexpr int kMaxPackClips = 1024;             // clips per loco_forward_packed
 struct StatusBlock {
     uint32_t magic;
     int32_t precision;                        // arithmetic mode of the forward this block describes
@@ -95,6 +96,10 @@ struct StatusBlock {
     const char* names[kRangeMaxStages];       // static strings of this library
     char msg[384];                            // non-empty: a range verdict known on the host (weights outside the planes' range)
     float words[kRangeMaxStages * kRangeShards];
+    // loco_forward_packed: per clip, the conv-layer-0 and the encoder frame counts of its OWN reference batch's padded length
+    // ([0, B): conv0 frames, [B, 2B): encoder frames).  Staged here because the block is host memory the caller keeps alive (and
+    // pinned) until the stream has completed the forward: the source of the host-to-device copy that opens the forward.
+    int32_t clip_tab[2 * kMaxPackClips];
 };
 // device side of the same: the first bytes of every workspace
 constexpr size_t kStatusDevBytes = (sizeof(float) * kRangeMaxStages * kRangeShards + 255) & ~size_t(255);
@@ -223,7 +228,7 @@ struct Plan {
     long L;
     long Tc[7];  // conv output lengths
     long T, M;
-    size_t off_frames, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1,
+    size_t off_frames, off_clip, off_c0scratch, off_a, off_b, off_x0, off_x1, off_tmp, off_ctx, off_qkv, off_qp, off_ffn, off_xs0, off_xs1,
         off_splitk, total;
     bool splitk;
 };
@@ -267,6 +272,7 @@ void carve_plan(const loco_encoder* e, Plan& p) {
         return at;
     };
     p.off_frames = take((size_t)B * sizeof(int32_t));
+    p.off_clip = take((size_t)2 * B * sizeof(int32_t));  // packed forward: per-clip conv0 / encoder frame counts (StatusBlock::clip_tab)
     p.off_c0scratch = take(conv0_scratch_bytes(B));
     p.off_a = take((size_t)B * p.Tc[0] * kConvDim * f);
     p.off_b = take((size_t)B * p.Tc[1] * kConvDim * f);
@@ -464,6 +470,9 @@ struct Bufs {
     float *bufA, *bufB, *x0, *x1, *tmp, *ctx, *qkv, *qp, *ffn;
     _Float16 *xs0, *xs1;
     char* c0scratch;
+    // packed forward (null otherwise): per clip, the conv-layer-0 frame count and the encoder frame count of its own reference batch
+    const int32_t* t0_clip = nullptr;
+    const int32_t* rows_clip = nullptr;
 };
 
 // ---- precision 0: every contraction on the exact-fp32 MFMA ------------------------------------------------------
@@ -486,7 +495,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
         Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
         HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
                                      W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), bufA,
-                                     bf.c0scratch, e->cfg.ln_eps, s));
+                                     bf.c0scratch, e->cfg.ln_eps, s, nullptr, nullptr, nullptr, bf.t0_clip));
     }
     float* cin = bufA;
     float* cout = bufB;
@@ -516,7 +525,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
     // ---- positional conv + sinusoid (HF :555-564)
     {
         Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
-        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s));
+        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s, bf.rows_clip));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
     }  // !skip_prenet
@@ -618,7 +627,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
         Bracket br(e, s, K_CONV0, 2.0 * 10 * B * (double)p.Tc[0] * kConvDim, outb + 8.0 * B * (double)L);
         HIP_TRY(launch_conv0_gn_gelu(wav, B, L, e->conv_w[0], W(e, pn + "feature_encoder.conv_layers.0.layer_norm.weight"),
                                      W(e, pn + "feature_encoder.conv_layers.0.layer_norm.bias"), nullptr, bf.c0scratch,
-                                     e->cfg.ln_eps, s, ihi, ilo, slot(kConvNames[0])));
+                                     e->cfg.ln_eps, s, ihi, ilo, slot(kConvNames[0]), bf.t0_clip));
     }
     float* cin = bf.bufA;
     float* cout = bf.bufB;
@@ -657,7 +666,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
         _Float16* glo = ghi + (size_t)B * kPosGroups * (T + kPosK) * kPosCg;
         {
             Bracket br(e, s, K_COPY, 0.0, 8.0 * M * kHidden);
-            HIP_TRY(launch_group_major_split(x1, ghi, glo, B, T, s, slot("feature_projection (input of pos_conv_embed)")));
+            HIP_TRY(launch_group_major_split(x1, ghi, glo, B, T, s, slot("feature_projection (input of pos_conv_embed)"), bf.rows_clip));
         }
         GemmSplitArgs a{};
         a.Ahi = ghi; a.Alo = glo; a.Whi = e->posg_s.hi; a.Wlo = e->posg_s.lo;
@@ -1123,8 +1132,9 @@ int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection,
 }
 
 namespace {
+// clip_tab: null, or (loco_forward_packed) the host table {conv0 frames [B], encoder frames [B]} of THIS (half-)batch's clips
 int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
-                float* const* hidden_states, char* ws, hipStream_t s) {
+                float* const* hidden_states, char* ws, hipStream_t s, const int32_t* clip_t0 = nullptr, const int32_t* clip_rows = nullptr) {
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* bufA = reinterpret_cast<float*>(ws + p.off_a);
     float* bufB = reinterpret_cast<float*>(ws + p.off_b);
@@ -1145,6 +1155,18 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
 
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    if (clip_t0) {
+        // packed forward: the per-clip tables follow the stream into the workspace; without a mask every sample of a clip's own
+        // reference batch counts, so its valid frames are that batch's frames (and a key mask is needed whatever the caller passed:
+        // clips of shorter batches end before the pack does)
+        int32_t* tab = reinterpret_cast<int32_t*>(ws + p.off_clip);
+        HIP_TRY(hipMemcpyAsync(tab, clip_t0, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(tab + B, clip_rows, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        if (!mask) HIP_TRY(hipMemcpyAsync(frames, tab + B, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        bufs.frames_or_null = frames;
+        bufs.t0_clip = tab;
+        bufs.rows_clip = tab + B;
+    }
     c.splitk = p.splitk ? reinterpret_cast<float*>(ws + p.off_splitk) : nullptr;
     return c.precision >= 1 ? forward_f16x3(e, c, p, wav, out, hidden_states, bufs, s) : forward_f32(e, p, wav, out, hidden_states, bufs, s);
 }
@@ -1153,7 +1175,8 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
 // the enqueue mutates is shared between calls except the lazily created side stream (side_mu), the profiling records (profiling
 // is a single-caller diagnostic mode) and the sinusoid table when a clip longer than any before makes it grow.
 int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
-                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream) {
+                 int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream,
+                 const int64_t* pad_len = nullptr) {
     if (!e || !wav || !out || !workspace || !st) return fail(LOCO_E_INVALID, "loco_forward: null argument");
     if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
     if (!e->speech_ready) return fail(LOCO_E_STATE, "loco_forward: this encoder was loaded without the speech prenet weights");
@@ -1172,6 +1195,19 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sin_rows(e, (int)p.T + 2, s);
     if (rc) return rc;
+    const int32_t *tab_t0 = nullptr, *tab_rows = nullptr;
+    if (pad_len) {  // loco_forward_packed: validate, then derive the two per-clip frame counts into the caller's status block
+        if (B > kMaxPackClips) return fail(LOCO_E_INVALID, "loco_forward_packed: %d clips > %d", B, kMaxPackClips);
+        for (int b = 0; b < B; ++b) {
+            if (pad_len[b] > L || loco_output_frames(pad_len[b]) < 1)
+                return fail(LOCO_E_INVALID, "loco_forward_packed: pad_len[%d] = %lld must lie in [400, L = %lld]", b, (long long)pad_len[b],
+                            (long long)L);
+            st->clip_tab[b] = (int32_t)conv_out_len(pad_len[b], kConvK[0], kConvS[0]);
+            st->clip_tab[B + b] = (int32_t)loco_output_frames(pad_len[b]);
+        }
+        tab_t0 = st->clip_tab;
+        tab_rows = st->clip_tab + B;
+    }
     Call c;
     c.precision = precision;
     c.st = st;
@@ -1179,7 +1215,7 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
     if ((rc = range_begin(e, c, s))) return rc;
     if (!dual) {
-        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s);
+        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s, tab_t0, tab_rows);
         if (rc) return rc;
         return range_end(c, s);
     }
@@ -1197,12 +1233,13 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
     // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
     c.dual = true;
-    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s);
+    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s, tab_t0, tab_rows);
     int rc1 = LOCO_OK;
     std::string first_error;
     if (rc) first_error = g_err;
     else rc1 = forward_one(e, c, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
-                           out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side);
+                           out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side, tab_t0 ? tab_t0 + B0 : nullptr,
+                           tab_rows ? tab_rows + B0 : nullptr);
     c.dual = false;
     if (!rc && rc1) first_error = g_err;
     const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves
@@ -1296,6 +1333,23 @@ int loco_forward_async(loco_encoder* e, int precision, const float* wav, const i
     if (rc) st->magic = 0;
     return rc;
 }
+
+int loco_forward_packed(loco_encoder* e, int precision, const float* wav, const int32_t* mask, int32_t B, int64_t L, const int64_t* pad_len,
+                        float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream,
+                        void* status) {
+    if (!e || !status || !pad_len) return fail(LOCO_E_INVALID, "loco_forward_packed: null argument");
+    if (precision != -1 && !loco_precision_name(precision))
+        return fail(LOCO_E_INVALID, "loco_forward_packed: precision must be -1 (the handle's mode) or one of " LOCO_PRECISION_MODES);
+    if (reinterpret_cast<uintptr_t>(status) & 7) return fail(LOCO_E_INVALID, "loco_forward_packed: the status block must be 8-byte aligned");
+    StatusBlock* st = reinterpret_cast<StatusBlock*>(status);
+    st->magic = 0;
+    const int rc = forward_impl(e, precision < 0 ? e->precision : precision, st, wav, mask, B, L, out, out_frames, hidden_states, workspace,
+                                workspace_bytes, stream, pad_len);
+    if (rc) st->magic = 0;
+    return rc;
+}
+
+int loco_max_pack_clips(void) { return kMaxPackClips; }
 
 int loco_status_check(const void* status, char* buf, size_t buflen) {
     const StatusBlock* st = as_status(status);

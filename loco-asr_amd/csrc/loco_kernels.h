@@ -101,7 +101,10 @@ struct GemmSplitArgs {
 };
 // x [B,T,768] fp32 -> fp16 hi/lo planes in group-major layout [B][16][T+128][48] with 64 zero frames before and after:
 // output frame t of group g then reads the CONTIGUOUS run rows t .. t+127 (128 taps x 48 channels = K 6144, lda = 48)
-hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot = nullptr);
+// rows_clip (device, [B], may be null): packed forward -- rows t >= rows_clip[b] of clip b read as zeros (the conv's zero padding
+// starts where the clip's own reference batch ends)
+hipError_t launch_group_major_split(const float* x, void* hi, void* lo, int B, int T, hipStream_t s, float* range_slot = nullptr,
+                                    const int32_t* rows_clip = nullptr);
 // folded positional-conv weight [g][tap][o][i] -> [g][o][tap*48 + i] (the GEMM's W, ldw = 6144)
 hipError_t launch_pos_w_for_gemm(const float* wf, float* out, hipStream_t s);
 hipError_t launch_attention_f16x3(const _Float16* qhi, const _Float16* qlo, const _Float16* khi, const _Float16* klo,
@@ -271,7 +274,9 @@ constexpr int kConv0Moments = 65;  // 10 first + 55 second moments
 size_t conv0_scratch_bytes(int B);
 hipError_t launch_conv0_gn_gelu(const float* wav, int B, long L, const float* w, const float* gn_w, const float* gn_b,
                                 float* out, void* scratch, float eps, hipStream_t s, void* out_hi = nullptr,
-                                void* out_lo = nullptr, float* range_slot = nullptr);
+                                void* out_lo = nullptr, float* range_slot = nullptr, const int32_t* t0_clip = nullptr);
+// t0_clip (device, [B], may be null): packed forward -- GroupNorm statistics of clip b over its first t0_clip[b] conv frames only,
+// frames beyond written as zeros
 hipError_t launch_frame_counts(const int32_t* mask, int B, long L, int32_t* frames, hipStream_t s);
 size_t normalize_scratch_bytes(int B);
 hipError_t launch_normalize_waveform(const float* wav, const int32_t* mask, int B, long L, float pad, float* out, void* scratch,
@@ -281,7 +286,7 @@ hipError_t launch_text_prenet(const int32_t* ids, const float* embed, int vocab,
                               float* out, hipStream_t s);
 hipError_t launch_text_pe_table(float* pe, int rows, hipStream_t s);
 hipError_t launch_pos_conv(const float* h, const float* wf, const float* bias, const float* sin_table,
-                           const int32_t* frames, float* out, int B, int T, hipStream_t s);
+                           const int32_t* frames, float* out, int B, int T, hipStream_t s, const int32_t* rows_clip = nullptr);
 hipError_t launch_attention(const float* qkv, const float* qp, const int32_t* frames, float* ctx, int B, int T,
                             hipStream_t s, void* ctx_hi = nullptr, void* ctx_lo = nullptr);
 

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ sin_table,
                                                           const int32_t* __restrict__ frames, float* __restrict__ out,
-                                                          int T) {
+                                                          int T, const int32_t* __restrict__ rows_clip) {
     __shared__ __attribute__((aligned(16))) float xl[PC_ROWS * PC_LD];
     const int b = blockIdx.z, g = blockIdx.y;
     const int t0 = blockIdx.x * PC_BM;
@@ -33,11 +33,12 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const float* __restric
     const int lr = lane & 15, kq = lane >> 4;
 
     const float* hb = h + (long)b * T * kHidden + g * kPosCg;
+    const int tin = rows_clip ? rows_clip[b] : T;  // packed forward: the clip's own reference batch ends here, zeros follow
     for (int f = tid; f < PC_ROWS * (kPosCg / 4); f += 256) {
         const int row = f / (kPosCg / 4), c4 = f % (kPosCg / 4);
         const int t = t0 - kPosK / 2 + row;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) v = *reinterpret_cast<const float4*>(hb + (long)t * kHidden + c4 * 4);
+        if (t >= 0 && t < tin) v = *reinterpret_cast<const float4*>(hb + (long)t * kHidden + c4 * 4);
         *reinterpret_cast<float4*>(xl + row * PC_LD + c4 * 4) = v;
     }
     __syncthreads();
@@ -109,10 +110,10 @@ __global__ __launch_bounds__(256, 2) void pos_conv_kernel(const float* __restric
 }
 
 hipError_t launch_pos_conv(const float* h, const float* wf, const float* bias, const float* sin_table,
-                           const int32_t* frames, float* out, int B, int T, hipStream_t s) {
+                           const int32_t* frames, float* out, int B, int T, hipStream_t s, const int32_t* rows_clip) {
     if (B <= 0 || T <= 0 || B > 65535) return hipErrorInvalidValue;
     dim3 grid((T + PC_BM - 1) / PC_BM, kPosGroups, B);
-    hipLaunchKernelGGL(pos_conv_kernel, grid, dim3(256), 0, s, h, wf, bias, sin_table, frames, out, T);
+    hipLaunchKernelGGL(pos_conv_kernel, grid, dim3(256), 0, s, h, wf, bias, sin_table, frames, out, T, rows_clip);
     return hipGetLastError();
 }
 

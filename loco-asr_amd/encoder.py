@@ -166,15 +166,22 @@ class _Slot:
 class ForwardTicket:
     """A forward that has been enqueued and not yet checked.  ``result()`` waits for it (an event, not a device-wide
     synchronisation), reads its numeric-range status and -- under range_policy "fp32" -- runs the batch once more on the
-    exact-fp32 kernels when the fp16 planes' range was left; then returns what ``forward`` would have returned."""
+    exact-fp32 kernels when the fp16 planes' range was left; then returns what ``forward`` would have returned (for a packed
+    forward: the list of per-batch outputs ``forward_packed`` returns).
 
-    def __init__(self, enc, slot, x, m, out, frames, precision):
+    A failure (range_policy "raise" on a batch outside the fp16 planes' range, a HIP error in the re-run) belongs to THIS ticket:
+    it is stored, the ticket is marked resolved and its slot released either way, and only ``result()`` of this ticket raises it
+    -- the slot's next forward, ``drain()`` and ``set_inflight()`` settle the ticket without re-raising somebody else's error."""
+
+    def __init__(self, enc, slot, x, m, out, frames, precision, pad_len=None, spans=None):
         self._enc, self._slot = enc, slot
         self._x, self._m = x, m  # kept alive until the forward has consumed them
         self._out, self._frames = out, frames
         self._precision = precision
+        self._pad_len, self._spans = pad_len, spans  # packed forward: per-clip padded lengths, (first clip, clips, frames) per batch
         self._done = torch.cuda.Event()
         self._resolved = False
+        self._error = None
         self._lock = threading.Lock()  # result() may be called from the thread that enqueues (slot reuse) and from a consumer thread
         self.used_fp32 = False
 
@@ -183,28 +190,47 @@ class ForwardTicket:
 
     def result(self):
         with self._lock:
-            return self._result_locked()
+            self._settle_locked()
+            if self._error is not None:
+                raise self._error
+            return self._value()
 
-    def _result_locked(self):
-        if not self._resolved:
-            enc, slot = self._enc, self._slot
+    def settle(self):
+        """Wait for the forward and release its slot; a failure stays with the ticket (``result()`` raises it)."""
+        with self._lock:
+            self._settle_locked()
+
+    def _value(self):
+        if self._spans is None:
+            return BaseModelOutput(last_hidden_state=self._out, hidden_states=None, attentions=None)
+        return [BaseModelOutput(last_hidden_state=self._out[b0:b0 + nb, :t], hidden_states=None, attentions=None)
+                for (b0, nb, t) in self._spans]
+
+    def _settle_locked(self):
+        if self._resolved:
+            return
+        enc, slot = self._enc, self._slot
+        try:
             self._done.synchronize()
             if enc.range_policy != "off" and self._precision != "f32":
                 rc = enc._lib.loco_status_check(C.c_void_p(slot.status.data_ptr()), None, 0)
                 if rc == -5 and enc.range_policy == "fp32":
                     with torch.cuda.device(self._out.device), torch.cuda.stream(slot.stream):
-                        enc._enqueue(slot, self._x, self._m, self._out, self._frames, "f32")
+                        extra = () if self._pad_len is None else (self._pad_len,)
+                        enc._enqueue(slot, self._x, self._m, self._out, self._frames, "f32", *extra)
                         slot.stream.synchronize()
                     self.used_fp32 = True
                 elif rc < 0:
                     _lib.check(rc, "loco_forward_async")
             enc.last_range_fallback = self.used_fp32
             enc.last_frames = self._frames
+        except BaseException as e:  # noqa: BLE001 -- stored; raised to the callers of this ticket's result() only
+            self._error = e
+        finally:
             self._resolved = True
             self._x = self._m = None
             if slot.ticket is self:
                 slot.ticket = None
-        return BaseModelOutput(last_hidden_state=self._out, hidden_states=None, attentions=None)
 
 
 class _Ref:
@@ -379,18 +405,25 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         """Resolve every forward still in flight (their tickets stay valid)."""
         for slot in self._slots:
             if slot.ticket is not None:
-                slot.ticket.result()
+                slot.ticket.settle()
 
-    def _enqueue(self, slot, x, m, out, frames, precision):
+    def _enqueue(self, slot, x, m, out, frames, precision, pad_len=None):
         B, L = x.shape
         need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
         if slot.workspace is None or slot.workspace.numel() < need:
             slot.workspace = None
             slot.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
-        _lib.check(self._lib.loco_forward_async(
-            self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), C.c_void_p(m.data_ptr()) if m is not None else None,
-            B, L, C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()),
-            slot.workspace.numel(), C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_async")
+        mp = C.c_void_p(m.data_ptr()) if m is not None else None
+        if pad_len is None:
+            _lib.check(self._lib.loco_forward_async(
+                self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, B, L, C.c_void_p(out.data_ptr()),
+                C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()), slot.workspace.numel(),
+                C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_async")
+        else:
+            _lib.check(self._lib.loco_forward_packed(
+                self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, B, L, (C.c_int64 * B)(*pad_len),
+                C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()),
+                slot.workspace.numel(), C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_packed")
 
     @torch.no_grad()
     def forward_async(self, input_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, **kwargs) -> ForwardTicket:
@@ -421,26 +454,108 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             if attention_mask.shape != x.shape:
                 raise ValueError(f"attention_mask {tuple(attention_mask.shape)} does not match input_values {tuple(x.shape)}")
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
+        return self._submit(x, m, T)
+
+    def _submit(self, x, m, T, pad_len=None, spans=None):
+        """Enqueue one (plain or packed) forward on the next slot.  ``out`` / ``frames`` are allocated on the CALLER's current
+        stream (the slot's stream is ordered behind it before the forward, and the caller's stream behind the forward's completion
+        event is what ``result()`` provides on the host): a consumer that uses them on its own stream after ``result()`` needs no
+        ``record_stream`` for the allocator's sake -- the block returns to the stream it came from."""
+        device = x.device
+        B = x.shape[0]
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % len(self._slots)
         if slot.ticket is not None:
-            slot.ticket.result()
+            slot.ticket.settle()
         with torch.cuda.device(device):
             self._sync_weights(device, T + 2)  # also grows the sinusoid table BEFORE anything is in flight on a longer clip
             _lib.check(self._lib.loco_set_streams(self._handle, int(self.streams)), "set_streams")
             cur = torch.cuda.current_stream(device)
+            out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+            frames = torch.empty((B,), dtype=torch.int32, device=device)
             slot.stream.wait_stream(cur)
             with torch.cuda.stream(slot.stream):
-                out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
-                frames = torch.empty((B,), dtype=torch.int32, device=device)
-                x.record_stream(slot.stream)
-                if m is not None:
-                    m.record_stream(slot.stream)
-                ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision)
-                self._enqueue(slot, x, m, out, frames, self.precision)
+                for t in (x, m, out, frames):
+                    if t is not None:
+                        t.record_stream(slot.stream)
+                ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision, pad_len, spans)
+                self._enqueue(slot, x, m, out, frames, self.precision, pad_len)
                 ticket._done.record(slot.stream)
         slot.ticket = ticket
         return ticket
+
+    # -- packed forward: several reference batches in one launch sequence (include/loco_asr.h, loco_forward_packed) ------------
+    def pack_batches(self, batches, device=None):
+        """Lay the clips of several reference batches out as ONE [B, L] problem: ``batches`` is a list of mappings with
+        ``input_values`` f32 [B_i, L_i] and optionally ``attention_mask`` [B_i, L_i] (what SpeechT5FeatureExtractor returns per
+        batch, …base…py:60), on the host or on the device.  Returns (wav [B, L], mask [B, L] or None, pad_len, spans) where clip b
+        keeps the padded length of its own batch (pad_len[b] = L_i) and spans[i] = (first clip, B_i, output frames of batch i).
+        Host inputs are packed in pinned memory and cross PCIe as one copy."""
+        if not batches:
+            raise ValueError("pack_batches: no batches")
+        device = device or self._device()
+        xs = [b["input_values"] for b in batches]
+        ms = [b.get("attention_mask") if hasattr(b, "get") else None for b in batches]
+        for x, mk in zip(xs, ms):
+            if x.dim() != 2:
+                raise ValueError(f"input_values must be [batch, samples], got {tuple(x.shape)}")
+            if mk is not None and mk.shape != x.shape:
+                raise ValueError(f"attention_mask {tuple(mk.shape)} does not match input_values {tuple(x.shape)}")
+        B = sum(int(x.shape[0]) for x in xs)
+        L = max(int(x.shape[1]) for x in xs)
+        L = (L + 7) // 8 * 8  # rows start 16-byte aligned: the mask counter's vector path
+        on_host = all(not x.is_cuda for x in xs)
+        kw = dict(pin_memory=True) if on_host else dict(device=device)
+        wav = torch.zeros((B, L), dtype=torch.float32, **kw)
+        mask = torch.zeros((B, L), dtype=torch.int32, **kw) if any(mk is not None for mk in ms) else None
+        pad_len, spans, b0 = [], [], 0
+        for x, mk in zip(xs, ms):
+            nb, li = int(x.shape[0]), int(x.shape[1])
+            t = int(self._lib.loco_output_frames(li))
+            if t < 1:
+                raise ValueError(f"input of {li} samples is shorter than one encoder frame (400 samples)")
+            wav[b0:b0 + nb, :li] = x
+            if mask is not None:
+                if mk is not None:
+                    mask[b0:b0 + nb, :li] = mk
+                else:
+                    mask[b0:b0 + nb, :li] = 1
+            pad_len += [li] * nb
+            spans.append((b0, nb, t))
+            b0 += nb
+        if on_host:
+            wav = wav.to(device, non_blocking=True)
+            mask = mask.to(device, non_blocking=True) if mask is not None else None
+        return wav, mask, pad_len, spans
+
+    @torch.no_grad()
+    def forward_packed_async(self, batches=None, *, packed=None) -> ForwardTicket:
+        """Enqueue the reference batches in ``batches`` (see pack_batches) -- or an already packed ``(wav, mask, pad_len, spans)``
+        -- as one launch sequence; ``ticket.result()`` is a list with one BaseModelOutput per batch whose ``last_hidden_state``
+        [B_i, T_i, 768] (a view into the pack's output) is what ``forward`` returns for that batch alone up to the fp32 summation
+        order of the GEMMs (<= 5e-6 relative L2).  The batches are NOT merged: GroupNorm statistics, the positional conv's zero
+        padding, sinusoid positions and the key mask all follow each clip's own batch (include/loco_asr.h)."""
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        device = self._device()
+        self._ensure_handle(device)
+        if self._weights_dirty:
+            self.drain()
+        if not self._slots:
+            self.set_inflight(2)
+        wav, mask, pad_len, spans = packed if packed is not None else self.pack_batches(batches, device)
+        if wav.device != device:
+            raise RuntimeError(f"module parameters are on {device} but the pack on {wav.device}")
+        if len(pad_len) != wav.shape[0]:
+            raise ValueError("pad_len must hold one entry per clip of the pack")
+        if wav.shape[0] > int(self._lib.loco_max_pack_clips()):
+            raise ValueError(f"a pack holds at most {int(self._lib.loco_max_pack_clips())} clips")
+        T = int(self._lib.loco_output_frames(wav.shape[1]))
+        return self._submit(wav, mask, T, [int(v) for v in pad_len], list(spans))
+
+    def forward_packed(self, batches=None, *, packed=None):
+        """``forward_packed_async(...).result()``: list of per-batch outputs."""
+        return self.forward_packed_async(batches, packed=packed).result()
 
     def workspace_bytes(self, batch: int, samples: int) -> int:
         self._ensure_handle(self._device())

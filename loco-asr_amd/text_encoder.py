@@ -161,17 +161,18 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % len(self._slots)
         if slot.ticket is not None:
-            slot.ticket.result()
+            slot.ticket.settle()
         with torch.cuda.device(device):
             self._sync_weights(device)
             cur = torch.cuda.current_stream(device)
+            # outputs come from the CALLER's stream (see the speech encoder's _submit): no record_stream duty for consumers
+            out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+            frames = torch.empty((B,), dtype=torch.int32, device=device)
             slot.stream.wait_stream(cur)
             with torch.cuda.stream(slot.stream):
-                out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
-                frames = torch.empty((B,), dtype=torch.int32, device=device)
-                ids32.record_stream(slot.stream)
-                if m is not None:
-                    m.record_stream(slot.stream)
+                for t_ in (ids32, m, out, frames):
+                    if t_ is not None:
+                        t_.record_stream(slot.stream)
                 ticket = ForwardTicket(self, slot, ids32, m, out, frames, self.precision)
                 self._enqueue(slot, ids32, m, out, frames, self.precision)
                 ticket._done.record(slot.stream)

@@ -1,0 +1,204 @@
+"""Packed forward (include/loco_asr.h, loco_forward_packed; encoder.forward_packed; extract.py --pack): G reference batches of
+two utterances (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:51-68) in ONE launch sequence, every clip
+carrying the padded length of its own batch -- GroupNorm statistics, the positional conv's zero padding, sinusoid positions and
+the key mask follow that batch, everything else is row-wise.  A pack must reproduce the one-batch forwards it replaces up to the
+fp32 summation order of the GEMMs (<= 5e-6 relative L2), padded frames included, and the oracle / HF goldens at the usual 2e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, record_figure
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from gpu_util import la, model, rel_l2
+
+PACK_TOL = 5e-6   # pack vs the one-pair forward: GEMM summation order only
+TOL = 2e-5        # vs oracle / HF golden
+
+
+def _pairs(n_pairs, lo_s=2.0, hi_s=6.0, seed_base=0):
+    """reference batches: pairs in corpus order of a SLURP-like ragged corpus (lo_s .. hi_s seconds)"""
+    lens = la.synth.mixed_lengths(2 * n_pairs, int(hi_s * 16000), min_fraction=lo_s / hi_s)
+    fe = la.SpeechT5FeatureExtractorMI355X()
+    out = []
+    for p in range(n_pairs):
+        b = fe(audio=[la.synth.clip(seed_base + 2 * p + j, lens[2 * p + j]) for j in (0, 1)], sampling_rate=16000, return_tensors="pt")
+        out.append(dict(input_values=b["input_values"], attention_mask=b["attention_mask"]))
+    return out
+
+
+def _cuda(b):
+    return {k: v.cuda() for k, v in b.items()}
+
+
+def test_packs_of_16_and_32_pairs_equal_the_one_pair_forwards_and_the_oracle(oracle):
+    """64 ragged pairs (2-6 s); every utterance including its batch's padded rows."""
+    m, sd = model()
+    enc = m.speecht5.encoder
+    batches = _pairs(64)
+    ref, frames_ref = [], []
+    for b in batches:
+        ref.append(enc(**_cuda(b)).last_hidden_state.clone())
+        frames_ref.append(enc.last_frames.cpu().tolist())
+    worst = {}
+    for G in (16, 32):
+        w = 0.0
+        for g0 in range(0, 64, G):
+            t = enc.forward_packed_async(batches[g0:g0 + G])   # host batches: packed in pinned memory, one H2D
+            outs = t.result()
+            assert not t.used_fp32
+            fr = enc.last_frames.cpu().tolist()
+            assert len(outs) == G
+            for i, o in enumerate(outs):
+                r = ref[g0 + i]
+                assert tuple(o.last_hidden_state.shape) == tuple(r.shape)
+                assert fr[2 * i:2 * i + 2] == frames_ref[g0 + i]
+                for c in (0, 1):   # per utterance, padded rows included
+                    e = rel_l2(o.last_hidden_state[c], r[c])
+                    w = max(w, e)
+                    assert e < PACK_TOL, (G, g0 + i, c, e)
+        worst[G] = w
+    # the same packs from DEVICE batches (packed by device-side copies): same bits as the host-packed form
+    dev_batches = [_cuda(b) for b in batches[:16]]
+    a = enc.forward_packed(dev_batches)
+    b_ = enc.forward_packed(batches[:16])
+    for x, y in zip(a, b_):
+        assert torch.equal(x.last_hidden_state, y.last_hidden_state)
+    # oracle, pair by pair (the pinned CPU restatement, run on this box)
+    worst_oracle = 0.0
+    outs = enc.forward_packed(batches[:32]) + enc.forward_packed(batches[32:])
+    for b, o in zip(batches, outs):
+        want = oracle.encode(b["input_values"].numpy(), b["attention_mask"].numpy(), sd)
+        e = rel_l2(o.last_hidden_state, want)
+        worst_oracle = max(worst_oracle, e)
+        assert e < TOL, e
+    record_figure("packed_vs_one_pair", worst_rel_l2_G16=worst[16], worst_rel_l2_G32=worst[32], worst_vs_oracle=worst_oracle)
+    print(f"packed vs one-pair forward: worst rel L2 {worst}; vs oracle {worst_oracle:.2e}")
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_g2_pair_inside_a_pack_reproduces_the_hf_golden(precision):
+    """The HF golden's ragged pair (5 s + 3 s) in the MIDDLE of a pack of longer and shorter batches, both arithmetic modes."""
+    g = golden("g2_5s_3s.npz")
+    rows = torch.from_numpy(g["rows"])
+    m, _ = model(precision=precision)
+    enc = m.speecht5.encoder
+    x, msk = la.synth.batch(g["lengths"])
+    g2 = dict(input_values=torch.from_numpy(x), attention_mask=torch.from_numpy(msk))
+    others = _pairs(6, seed_base=500)
+    outs = enc.forward_packed(others[:3] + [g2] + others[3:])
+    y = outs[3].last_hidden_state
+    assert tuple(y.shape) == (2, 249, 768)
+    assert enc.last_frames.cpu().tolist()[6:8] == [249, 149]
+    assert rel_l2(y[:, rows], g["hidden_states"][12]) < TOL
+    assert abs(float(y.double().norm()) / g["hidden_stats"][12, 0] - 1) < 1e-5
+
+
+def test_pack_without_masks_and_with_one_stream_and_a_single_batch():
+    m, _ = model()
+    enc = m.speecht5.encoder
+    batches = _pairs(8, lo_s=1.0, hi_s=3.0, seed_base=40)
+    # no attention_mask: every sample of a batch is present (HF: no key mask, all positions valid) -- per batch
+    nomask = [dict(input_values=b["input_values"]) for b in batches]
+    ref = [enc(input_values=b["input_values"].cuda()).last_hidden_state.clone() for b in nomask]
+    outs = enc.forward_packed(nomask)
+    for o, r in zip(outs, ref):
+        assert rel_l2(o.last_hidden_state, r) < PACK_TOL
+    # mixed: some batches with a mask, some without
+    mixed = [b if i % 2 else dict(input_values=b["input_values"]) for i, b in enumerate(batches)]
+    refm = [enc(**_cuda(b)).last_hidden_state.clone() for b in mixed]
+    for o, r in zip(enc.forward_packed(mixed), refm):
+        assert rel_l2(o.last_hidden_state, r) < PACK_TOL
+    # the two half-batch schedule against one in-order pass: the same arithmetic per row
+    big = _pairs(12, lo_s=4.0, hi_s=6.0, seed_base=80)   # 24 clips x ~250 frames: halves of >= 1024 frames -> two streams
+    enc.streams = 2
+    two = [o.last_hidden_state.clone() for o in enc.forward_packed(big)]
+    enc.streams = 1
+    one = [o.last_hidden_state.clone() for o in enc.forward_packed(big)]
+    enc.streams = 2
+    for a, b in zip(one, two):
+        assert rel_l2(a, b) < PACK_TOL
+    # run-to-run determinism of a pack
+    again = [o.last_hidden_state for o in enc.forward_packed(big)]
+    for a, b in zip(two, again):
+        assert torch.equal(a, b)
+    # a pack of ONE batch is that batch
+    solo = enc.forward_packed(batches[:1])[0].last_hidden_state
+    assert rel_l2(solo, enc(**_cuda(batches[0])).last_hidden_state) < PACK_TOL
+
+
+def test_range_status_is_per_pack_and_the_fp32_rerun_is_packed_too(oracle):
+    """A model whose FFN intermediate exceeds fp16's maximum: the pack's status reports it, policy "fp32" re-runs THE PACK on the
+    exact-fp32 kernels (same per-clip semantics), policy "raise" raises on this ticket only and leaves the slot usable."""
+    sd = la.synth.encoder_state_dict(0, layers=2)
+    ovf = dict(sd)
+    k1, k2 = "wrapped_encoder.layers.0.feed_forward.intermediate_dense.bias", "wrapped_encoder.layers.0.feed_forward.output_dense.weight"
+    ovf[k1] = sd[k1] + np.float32(1.0e5)
+    ovf[k2] = sd[k2] * np.float32(1e-5)
+    pre, enc_sd = la.synth.split_state_dict(ovf)
+    mo = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                          {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=2).cuda()
+    eo = mo.speecht5.encoder
+    batches = _pairs(4, lo_s=0.6, hi_s=1.5, seed_base=900)
+    eo.set_inflight(2)
+    t = eo.forward_packed_async(batches)
+    outs = t.result()
+    assert t.used_fp32 and eo.last_range_fallback
+    for b, o in zip(batches, outs):
+        want = oracle.encode(b["input_values"].numpy(), b["attention_mask"].numpy(), ovf)
+        assert torch.isfinite(o.last_hidden_state).all() and rel_l2(o.last_hidden_state, want) < TOL
+    # under a SUSTAINED "raise" policy a failed ticket must not poison its slot
+    eo.range_policy = "raise"
+    bad = [eo.forward_packed_async(batches) for _ in range(2)]            # both slots carry a failing forward
+    more = [eo.forward_packed_async(batches[:2]) for _ in range(3)]       # slots reused three times: settles the failed tickets
+    for tk in bad + more:
+        with pytest.raises(la.LocoError, match="feed_forward intermediate"):
+            tk.result()
+        with pytest.raises(la.LocoError):   # the error stays with the ticket
+            tk.result()
+    eo.drain()                                                            # nothing left to re-raise
+    pair = _cuda(batches[0])
+    t1 = eo.forward_async(**pair)
+    with pytest.raises(la.LocoError):
+        t1.result()
+    eo.set_inflight(1)                                                    # ... and neither does re-slotting
+    eo.range_policy = "fp32"
+    assert torch.isfinite(eo.forward_async(**pair).result().last_hidden_state).all()
+
+
+def test_packed_c_abi_error_codes():
+    m, _ = model()
+    enc = m.speecht5.encoder
+    enc(input_values=torch.zeros(1, 16000, device="cuda"))   # weights loaded
+    lib = enc._lib
+    B, L = 4, 16000
+    x = torch.zeros(B, L, device="cuda")
+    out = torch.empty(B, int(lib.loco_output_frames(L)), 768, device="cuda")
+    ws = torch.empty(int(lib.loco_workspace_bytes(enc._handle, B, L)), dtype=torch.uint8, device="cuda")
+    status = torch.zeros(int(lib.loco_status_bytes()), dtype=torch.uint8).pin_memory()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(pad, b=B, status_=status, ws_bytes=None):
+        arr = (C.c_int64 * len(pad))(*pad) if pad is not None else None
+        return lib.loco_forward_packed(enc._handle, 1, C.c_void_p(x.data_ptr()), None, b, L, arr, C.c_void_p(out.data_ptr()), None, None,
+                                       C.c_void_p(ws.data_ptr()), ws.numel() if ws_bytes is None else ws_bytes, st,
+                                       C.c_void_p(status_.data_ptr()) if status_ is not None else None)
+
+    assert call([L, L, 8000, 8000]) == 0
+    torch.cuda.synchronize()
+    assert lib.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) in (0, -5)   # zeros in: range verdict either way, a valid block
+    assert call([L, L, L + 1, L]) == -1 and b"pad_len[2]" in lib.loco_last_error()
+    assert call([L, L, 399, L]) == -1
+    assert call(None) == -1
+    assert call([L] * B, status_=None) == -1
+    assert call([L] * B, ws_bytes=1024) == -3
+    assert lib.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) == -1   # a failed enqueue leaves no valid status
+    assert int(lib.loco_max_pack_clips()) >= 256
+    with pytest.raises(ValueError):
+        enc.forward_packed([])
+    with pytest.raises(ValueError, match="shorter than one encoder frame"):
+        enc.forward_packed([dict(input_values=torch.zeros(2, 300))])
