@@ -171,6 +171,145 @@ def gather_ragged(local: torch.Tensor, local_ids: Sequence[int], n_total: int, g
     return res
 
 
+def _on(stream):
+    import contextlib
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+
+class RaggedGatherPipeline:
+    """``gather_ragged`` for a LOOP of rounds, overlapped with the rounds that follow (extract.py --gather; configs[3]: windows of
+    a podcast dealt to 8 ranks, every rank's embeddings gathered).  Per round TWO collectives instead of three, none of them
+    waited for in the round that issues it, and no host read of device metadata on the critical path:
+
+      round k    submit(local_k)  ->  all_gather_into_tensor of ONE int64 row per rank [B_loc, T_loc, ids[cap], rows[cap]], async
+      round k+1  the metadata of round k has long arrived: read it (a round late, so the read waits for nothing), pad local_k into
+                 a reused send buffer [b_max, t_max, D] and start the payload all_gather_into_tensor, async
+      round k+2  wait for the payload of round k (issued a round ago) and hand its rows out
+
+    ``submit`` returns the finished rows of the round two calls back as a list of (global unit index, tensor [rows, D]) -- views
+    into that round's receive buffer, identical on every rank -- and ``flush`` drains the last two rounds.  ``cap`` = the largest
+    number of units any rank contributes in one round (batch size x batches per round): it fixes the metadata row, so that no
+    shape has to be agreed first.  ``rows[i]`` (default: all T_loc) are the frames of unit i worth keeping: a packed forward's
+    clips end where their own reference batch ends.  Send buffers are reused from round to round; a receive buffer is allocated
+    per round (torch's caching allocator: no driver call in steady state) because its consumers -- the sink's D2H copies on their
+    own stream -- outlive the round and protect it with record_stream, which a fixed ring could not honour without a release
+    handshake.  Works with any backend (gloo on CPU in tests/test_dp_gloo.py, RCCL on device tensors)."""
+
+    def __init__(self, cap: int, dim: int = 768, group=None):
+        self.cap, self.dim, self.group = int(cap), int(dim), group
+        self.world, self.rank = _world(group)
+        self.skip = _skip_collective(self.world)
+        self._stages = []        # rounds in flight, oldest first
+        self._send = [None, None]
+        self._send_work = [None, None]
+        self._k = 0
+        self._stream = None      # collectives and their staging run beside the caller's stream
+        self.collectives = 0
+
+    def _side(self, device):
+        if device.type != "cuda":
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device)
+        return self._stream
+
+    def _start_meta(self, local, ids, rows, device):
+        n = 0 if local is None else int(local.shape[0])
+        if n > self.cap:
+            raise ValueError(f"{n} units in one round > cap {self.cap}")
+        t = 0 if local is None else int(local.shape[1])
+        row = torch.full((2 + 2 * self.cap,), -1, dtype=torch.int64)
+        row[0], row[1] = n, t
+        if n:
+            row[2:2 + n] = torch.tensor(list(ids), dtype=torch.int64)
+            row[2 + self.cap:2 + self.cap + n] = torch.tensor([t] * n if rows is None else [int(r) for r in rows], dtype=torch.int64)
+        st = dict(local=local, k=self._k, ready=None)
+        self._k += 1
+        side = self._side(device)
+        if side is not None and local is not None:  # whatever produced `local` on the caller's stream comes first
+            st["ready"] = torch.cuda.Event()
+            st["ready"].record(torch.cuda.current_stream(device))
+        with _on(side):
+            meta = row.to(device) if device.type == "cuda" else row
+            meta_all = torch.empty((self.world * row.numel(),), dtype=torch.int64, device=device)
+            st["meta"], st["meta_all"] = meta, meta_all
+            st["meta_work"] = dist.all_gather_into_tensor(meta_all, meta, group=self.group, async_op=True)
+        self.collectives += 1
+        return st
+
+    def _start_payload(self, st, device):
+        side = self._side(device)
+        with _on(side):
+            st["meta_work"].wait()
+            mh = st["meta_all"].cpu().view(self.world, -1)  # issued a round ago: complete; on the side stream, so nothing else is waited for
+            st["meta_host"] = mh
+            bmax, tmax = max(1, int(mh[:, 0].max())), max(1, int(mh[:, 1].max()))
+            slot = st["k"] & 1
+            if self._send_work[slot] is not None:
+                self._send_work[slot].wait()  # the collective that last read this send buffer (two rounds ago: long complete)
+            buf = self._send[slot]
+            need = bmax * tmax * self.dim
+            if buf is None or buf.numel() < need or buf.device != device:
+                buf = torch.empty(need, dtype=torch.float32, device=device)
+                self._send[slot] = buf
+            pad = buf[:need].view(bmax, tmax, self.dim)
+            local = st["local"]
+            if local is not None:
+                if st["ready"] is not None:
+                    side.wait_event(st["ready"])
+                pad[:local.shape[0], :local.shape[1]].copy_(local)
+                if side is not None:
+                    local.record_stream(side)
+            out = torch.empty((self.world * bmax, tmax, self.dim), dtype=torch.float32, device=device)
+            st["out"], st["bmax"] = out, bmax
+            st["pay_work"] = dist.all_gather_into_tensor(out, pad, group=self.group, async_op=True)
+            self._send_work[slot] = st["pay_work"]
+            st["local"] = None
+        self.collectives += 1
+
+    def _finish(self, st):
+        st["pay_work"].wait()  # on the CALLER's current stream: what it enqueues next sees the gathered rows
+        mh, bmax, out = st["meta_host"], st["bmax"], st["out"]
+        if out.is_cuda:
+            out.record_stream(torch.cuda.current_stream(out.device))  # allocated on the side stream, consumed on the caller's
+        res = []
+        for r in range(self.world):
+            for row in range(int(mh[r, 0])):
+                res.append((int(mh[r, 2 + row]), out[r * bmax + row, :int(mh[r, 2 + self.cap + row])]))
+        return res
+
+    def submit(self, local, ids, rows=None, device=None):
+        """Start the gather of this round's [B_loc, T_loc, D] (``None`` / empty ids when this rank has run out of units) and
+        return the finished rows of the round two calls back."""
+        if local is not None and local.shape[0] == 0:
+            local = None
+        if self.skip:
+            if local is None:
+                return []
+            return [(int(g), local[i, :(local.shape[1] if rows is None else int(rows[i]))]) for i, g in enumerate(ids)]
+        device = local.device if local is not None else torch.device(device if device is not None else "cpu")
+        if local is not None and local.is_cuda:
+            local = local.contiguous()
+        done = []
+        if len(self._stages) == 2:
+            done = self._finish(self._stages.pop(0))
+        if self._stages:
+            self._start_payload(self._stages[-1], device)
+        self._stages.append(self._start_meta(local, ids if local is not None else [], rows, device))
+        return done
+
+    def flush(self, device=None):
+        """Drain the rounds still in flight (call once, after the last submit, on every rank)."""
+        done = []
+        while self._stages:
+            st = self._stages[0]
+            dev = st["meta_all"].device
+            if "pay_work" not in st:
+                self._start_payload(st, dev)
+            done += self._finish(self._stages.pop(0))
+        return done
+
+
 def encode_sharded(encode_fn: Callable, clips: Sequence, make_batch: Callable, device, group=None, max_batch: int = 2,
                    bucket_by_length: bool = False):
     """Encode `clips` (list of 1-D waveforms) data-parallel and return the per-clip embeddings on every rank.

@@ -200,6 +200,11 @@ class ForwardTicket:
         with self._lock:
             self._settle_locked()
 
+    def packed_output(self):
+        """After ``result()`` of a packed forward: (out [B, T, 768] of the whole pack, spans [(first clip, clips, frames) per batch])
+        -- for consumers that move the pack as ONE tensor (the sink's single D2H copy) instead of batch by batch."""
+        return self._out, self._spans
+
     def _value(self):
         if self._spans is None:
             return BaseModelOutput(last_hidden_state=self._out, hidden_states=None, attentions=None)

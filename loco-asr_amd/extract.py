@@ -209,6 +209,15 @@ def main(argv=None):
                          "a pair of 5 s clips alone cannot fill 256 CUs.  1 = one batch at a time, as the reference runs; 0 (default) = "
                          "4 for utterances, 1 for --window-seconds >= 60 (a pair of 10-minute windows fills the chip by itself and "
                          "every slot would hold a 15 GB workspace)")
+    ap.add_argument("--pack", type=int, default=0,
+                    help="encode G of the reference's batches as ONE launch sequence (loco_forward_packed): the batches themselves are "
+                         "untouched -- corpus-order pairs, every clip keeps the padded length of its own batch for GroupNorm, the "
+                         "positional conv, positions and the key mask -- so the embeddings equal those of --inflight to the fp32 "
+                         "summation order of the GEMMs (<= 5e-6 relative L2), not bit for bit.  0 (default) = off.  32 is a good value "
+                         "for 2-6 s utterances; --inflight then counts packs (default 2)")
+    ap.add_argument("--pack-window", type=int, default=8,
+                    help="with --pack: batches are sorted by padded length inside windows of this many packs before they are packed "
+                         "(which batches share a pack does not change any embedding; short batches just do not idle in long packs)")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
@@ -296,51 +305,96 @@ def main(argv=None):
         my_batches = dp.shard_batches(len(items), args.batch_size, world, rank)
         n_rounds = dp.rounds(len(items), args.batch_size, world)  # equal on all ranks: collectives line up
 
-    def host_batch(rnd):
-        """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads,
-        several BATCHES at a time (a batch of the reference is two clips: parallelism inside one would be two threads wide)."""
-        idx = my_batches[rnd] if rnd < len(my_batches) else []
-        if not idx:
-            return idx, None
+    pack, pack_window = max(0, args.pack), max(1, args.pack_window)
+    if pack and args.bucket_by_length:
+        raise SystemExit("--pack keeps the reference's batches (it packs WHOLE batches); --bucket-by-length re-forms them: use one or the other")
+    # --pack G: a "round" is one pack of up to G of this rank's batches; equal on all ranks, so that collectives line up
+    n_packs = (n_rounds + pack - 1) // pack if pack else 0
+    n_tasks = (n_packs + pack_window - 1) // pack_window if pack else n_rounds
+
+    def host_features(idx):
+        """decode / synthesise the clips of ONE reference batch, pad and mask them (SpeechT5FeatureExtractor, …base…py:51-65)"""
         # a reference batch is two clips: decoded one after the other, the parallelism is across batches; a throughput batch
         # (--batch-size 32: 32 files of 30 s) is decoded by its own pool, or the GPU waits for one thread to read 30 MB of audio
         clips = list(clip_pool.map(fetch, idx)) if clip_pool is not None and len(idx) >= 8 else [fetch(i) for i in idx]
         if any(torch.is_tensor(c) for c in clips):  # some files were resampled on the device: the whole batch is padded there
             clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
-        feats = processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        return processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+
+    def host_batch(rnd):
+        """Everything the host does for one batch: decode, pad, mask (pinned memory) -- run ahead of the GPU on worker threads,
+        several BATCHES at a time (a batch of the reference is two clips: parallelism inside one would be two threads wide)."""
+        idx = my_batches[rnd] if rnd < len(my_batches) else []
+        if not idx:
+            return [(idx, None)]
         # the H2D copies are enqueued HERE, by the loader thread (pinned source, non-blocking, the default stream): the thread that
         # enqueues forwards only waits for the future; forward_async orders its stream behind the default stream
-        return idx, feats.to(device)
+        return [(idx, host_features(idx).to(device))]
+
+    def host_window(w):
+        """--pack: the host side of one WINDOW of pack_window packs.  The window's reference batches are decoded and padded one by
+        one -- each stays the batch the reference forms -- then sorted by padded length and cut into packs of G (any set of
+        batches may share a pack, include/loco_asr.h: sorting only removes the rows a short batch would idle in a long pack);
+        each pack is laid out in pinned memory and crosses PCIe as one copy (encoder.pack_batches)."""
+        p0, p1 = w * pack_window, min(n_packs, (w + 1) * pack_window)
+        mine = my_batches[p0 * pack:p1 * pack]  # may be short or empty on a rank that has run out
+        feats = [host_features(idx) for idx in mine]
+        if getattr(processor, "normalize_on_device", False):
+            feats = [f.to(device) for f in feats]  # the deferred normaliser runs per BATCH, before batches are packed
+        order = sorted(range(len(mine)), key=lambda i: (int(feats[i]["input_values"].shape[1]), i))
+        out = []
+        for g0 in range(0, len(order), pack):
+            sel = order[g0:g0 + pack]
+            out.append(([mine[i] for i in sel], encoder.pack_batches([feats[i] for i in sel], device)))
+        out += [([], None)] * ((p1 - p0) - len(out))  # empty contributions keep the collectives lined up
+        return out
 
     def on_device(_device=device):  # loader threads start on GPU 0: select the rank's GPU for anything they do there
         torch.cuda.set_device(_device)
 
     from concurrent.futures import ThreadPoolExecutor
-    inflight = args.inflight if args.inflight > 0 else (1 if args.window_seconds >= 60 else 4)
+    inflight = args.inflight if args.inflight > 0 else (1 if args.window_seconds >= 60 else (2 if pack else 4))
     # the window cache of one decoded recording is not thread-safe: windows are prepared by ONE thread, in order
     n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
     pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None
     clip_pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 1 and args.batch_size >= 8 and args.window_seconds <= 0 else None
-    ahead = max(2, 2 * inflight, n_loaders)  # batches being prepared while others are on the GPU
-    pending = [pool.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if pool else []
+    host_task = host_window if pack else host_batch
+    ahead = max(2, n_loaders) if pack else max(2, 2 * inflight, n_loaders)  # tasks being prepared while others are on the GPU
+    pending = [pool.submit(host_task, r) for r in range(min(ahead, n_tasks))] if pool else []
     encoder = model.speecht5.encoder
-    if inflight > 1:
-        encoder.set_inflight(inflight)
+    if inflight > 1 or pack:
+        encoder.set_inflight(max(1, inflight))
     gathers = 0
+    gatherer = dp.RaggedGatherPipeline(cap=args.batch_size * max(1, pack)) if args.gather and collective else None
 
-    def finish(idx, emb):
-        """What follows a batch's forward: the optional gather, then the sink -- in batch order, whatever finished first."""
+    def write_gathered(done):
+        if rank == 0:
+            for gid, e in done:
+                sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
+
+    def finish(meta, res):
+        """What follows a forward: the optional gather, then the sink -- in order, whatever finished first.  meta = the unit
+        indices of one batch, or (--pack) the list of such lists of one pack; res = BaseModelOutput / ticket / None."""
         nonlocal gathers, frames_done
-        if args.gather and collective:
-            embs = dp.gather_ragged(emb, idx, len(items))  # the one large collective of the step
+        if pack:
+            if res is not None:
+                res.result()
+                emb, spans = res.packed_output()
+                idx = [i for b in meta for i in b]
+                rows = [t for (_, nb, t) in spans for _ in range(nb)]
+                frames_done += sum(nb * t for (_, nb, t) in spans)
+            else:
+                emb, idx, rows = None, [], None
+        else:
+            out = res.result() if hasattr(res, "result") else res
+            emb, idx, rows = (out.last_hidden_state if out is not None else None), meta, None
+            if emb is not None:
+                frames_done += int(emb.shape[0]) * int(emb.shape[1])
+        if gatherer is not None:
+            write_gathered(gatherer.submit(emb, idx, rows, device))  # two collectives per round, both overlapped (dp.py)
             gathers += 1
-            if rank == 0:
-                for gid, e in enumerate(embs):
-                    if e is not None:
-                        sink.submit([items[gid][0]], e[None], encode_labels([items[gid][4]]))
         elif idx:
-            sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]))
-        frames_done += int(emb.shape[0]) * int(emb.shape[1])
+            sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]), rows=rows, chunk=8 if pack else 0)
 
     import queue
     import threading
@@ -348,9 +402,8 @@ def main(argv=None):
     frames_done = 0
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter()
-    empty = torch.zeros((0, 1, 768), dtype=torch.float32, device=device)
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format, workers=args.sink_threads,
-                                                 max_pending=max(4, 4 * inflight)) as sink:
+                                                 max_pending=max(4, 4 * inflight, 16 * (pack > 0))) as sink:
         # Two host threads share the loop when batches are in flight: this one stages (H2D) and enqueues forwards, the consumer
         # waits for each batch IN ORDER (an event, not a device-wide synchronisation), checks its range status and hands it to the
         # gather / the sink.  The queue is bounded: at most `inflight` batches wait behind the one being finished.
@@ -365,65 +418,81 @@ def main(argv=None):
                         item = todo.get()
                         if item is None:
                             return
-                        i0, t0 = item
-                        out = t0.result() if hasattr(t0, "result") else t0
-                        finish(i0, out.last_hidden_state if out is not None else empty)
+                        finish(*item)
             except BaseException as e:  # noqa: BLE001 -- re-raised on the producing thread
                 failure.append(e)
                 while todo.get() is not None:  # keep draining so that the producer never blocks on a dead consumer
                     pass
 
-        consumer = threading.Thread(target=consume, name="loco-finish") if inflight > 1 else None
+        consumer = threading.Thread(target=consume, name="loco-finish") if (inflight > 1 or pack) else None
         if consumer:
             consumer.start()
         try:
             prof = [0.0] * 4 if os.environ.get("LOCO_EXTRACT_PROFILE") == "1" else None  # seconds: wait for the staged batch, H2D, enqueue, hand-over
             tick = time.perf_counter
-            for rnd in range(n_rounds):
+            for rnd in range(n_tasks):
                 if failure:
                     break
                 t_a = tick()
                 if pool:
-                    idx, feats = pending.pop(0).result()
-                    if rnd + ahead < n_rounds:
-                        pending.append(pool.submit(host_batch, rnd + ahead))
+                    work = pending.pop(0).result()
+                    if rnd + ahead < n_tasks:
+                        pending.append(pool.submit(host_task, rnd + ahead))
                 else:
-                    idx, feats = host_batch(rnd)
+                    work = host_task(rnd)
                 t_b = tick()
-                if not idx:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
-                    item = (idx, None)
-                    t_c = t_b
-                else:
-                    on_dev = feats if feats["input_values"].is_cuda else feats.to(device)
-                    t_c = tick()
-                    item = (idx, encoder.forward_async(**on_dev) if inflight > 1 else encoder(**on_dev))
-                t_d = tick()
-                if consumer:
-                    todo.put(item)
-                else:
-                    finish(item[0], item[1].last_hidden_state if item[1] is not None else empty)
-                if prof is not None:
-                    t_e = tick()
-                    for k_, v_ in enumerate((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)):
-                        prof[k_] += v_
+                for meta, feats in work:
+                    t_b2 = tick()
+                    if feats is None:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
+                        item = (meta, None)
+                        t_c = t_b2
+                    elif pack:
+                        t_c = t_b2
+                        item = (meta, encoder.forward_packed_async(packed=feats))
+                    else:
+                        on_dev = feats if feats["input_values"].is_cuda else feats.to(device)
+                        t_c = tick()
+                        item = (meta, encoder.forward_async(**on_dev) if inflight > 1 else encoder(**on_dev))
+                    t_d = tick()
+                    if consumer:
+                        todo.put(item)
+                    else:
+                        finish(*item)
+                    if prof is not None:
+                        t_e = tick()
+                        for k_, v_ in enumerate((t_b - t_a, t_c - t_b2, t_d - t_c, t_e - t_d)):
+                            prof[k_] += v_
+                        t_a = t_b  # the wait is charged to the task's first item only
             if prof is not None:
-                print("main thread, ms per batch: wait for the staged batch %.3f, H2D %.3f, enqueue %.3f, hand-over / finish %.3f"
-                      % tuple(1e3 * v_ / max(1, n_rounds) for v_ in prof))
+                print("main thread, ms per %s: wait for the staged batch %.3f, H2D %.3f, enqueue %.3f, hand-over / finish %.3f"
+                      % (("pack" if pack else "batch",) + tuple(1e3 * v_ / max(1, n_packs if pack else n_rounds) for v_ in prof)))
         finally:
             if consumer:
                 todo.put(None)
                 consumer.join()
         if failure:
+            if collective:
+                # the other ranks are (or will be) blocked in this round's collectives: a rank that stops contributing must take the
+                # job down, not leave it hanging -- the launcher (torchrun) tears the other ranks down when one exits non-zero
+                import traceback
+                traceback.print_exception(type(failure[0]), failure[0], failure[0].__traceback__)
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(13)
             raise failure[0]
+        if gatherer is not None:
+            write_gathered(gatherer.flush())
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter() - t_loop  # decode / synthesis -> batching -> encoder -> sink, files closed
     n_mine = sum(len(b) for b in my_batches)
     print(f"Encoded {n_mine} utterances ({frames_done} frames, padded frames included) in {t_loop:.3f} s: "
-          f"{n_mine / max(t_loop, 1e-9):.1f} utterances/s, {frames_done / max(t_loop, 1e-9):,.0f} frames/s (--inflight {inflight})")
-    stats = {"utterances": n_mine, "frames": frames_done, "seconds": t_loop, "inflight": inflight}
+          f"{n_mine / max(t_loop, 1e-9):.1f} utterances/s, {frames_done / max(t_loop, 1e-9):,.0f} frames/s "
+          f"(--inflight {inflight}{f', --pack {pack}' if pack else ''})")
+    stats = {"utterances": n_mine, "frames": frames_done, "seconds": t_loop, "inflight": inflight, "pack": pack}
     if args.gather and collective:
         import torch.distributed as dist
-        print(f"Embedding gathers issued: {gathers} (backend {dist.get_backend()}, world size {world})")
+        print(f"Embedding gathers issued: {gathers} rounds, {gatherer.collectives} collectives (backend {dist.get_backend()}, world size {world})")
+        stats["gather_rounds"], stats["collectives"] = gathers, gatherer.collectives
     for ex in (pool, clip_pool):
         if ex is not None:
             ex.shutdown()

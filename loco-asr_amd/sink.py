@@ -64,13 +64,14 @@ class EmbeddingSink:
                 self._q.task_done()
                 return
             try:
-                ids, host, targets, event = item
+                ids, host, targets, event, rows = item
                 if event is not None:
                     event.synchronize()
                 arr = host.numpy()
                 for i, sid in enumerate(ids):
                     # np.array(...) detaches each utterance from the pinned staging buffer before pickling
-                    write_one(self.folder, sid, np.array(arr[i]), np.asarray(targets[i]), self.fmt)
+                    emb = arr[i] if rows is None else arr[i, :rows[i]]
+                    write_one(self.folder, sid, np.array(emb), np.asarray(targets[i]), self.fmt)
                 with self._lock:
                     self.written += len(ids)
             except BaseException as e:  # surfaced on the next submit()/close()
@@ -78,12 +79,15 @@ class EmbeddingSink:
             finally:
                 self._q.task_done()
 
-    def submit(self, ids: Sequence, embeddings: torch.Tensor, targets):
-        """embeddings [B, T, 768] on any device; returns as soon as the D2H copy is enqueued."""
+    def submit(self, ids: Sequence, embeddings: torch.Tensor, targets, rows: Optional[Sequence[int]] = None, chunk: int = 0):
+        """embeddings [B, T, 768] on any device; returns as soon as the D2H copy is enqueued.  ``rows`` (packed forward: the
+        output of several reference batches in one tensor) keeps the first rows[i] frames of utterance i -- the frames of ITS OWN
+        batch, that batch's padded frames included -- instead of all T; ``chunk`` > 0 hands the utterances to the writer threads
+        in groups of that many (one D2H copy, several writers)."""
         if self._err:
             raise self._err
-        if len(ids) != embeddings.shape[0] or len(targets) != len(ids):
-            raise ValueError("ids / embeddings / targets disagree on the batch size")
+        if len(ids) != embeddings.shape[0] or len(targets) != len(ids) or (rows is not None and len(rows) != len(ids)):
+            raise ValueError("ids / embeddings / targets / rows disagree on the batch size")
         event = None
         if embeddings.is_cuda:
             dev = embeddings.device
@@ -100,7 +104,11 @@ class EmbeddingSink:
                 event.record(self._copy_stream)
         else:
             host = embeddings.detach().clone()
-        self._q.put((list(ids), host, [np.asarray(t) for t in targets], event))
+        ids, targets = list(ids), [np.asarray(t) for t in targets]
+        rows = [int(r) for r in rows] if rows is not None else None
+        step = chunk if chunk > 0 else max(1, len(ids))
+        for a in range(0, len(ids), step):
+            self._q.put((ids[a:a + step], host[a:a + step], targets[a:a + step], event, rows[a:a + step] if rows is not None else None))
 
     def close(self):
         for _ in self._threads:

@@ -108,3 +108,61 @@ def _overlap_worker(rank, world, port):
 
 def test_overlapped_gather_two_ranks():
     mp.spawn(_overlap_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+def _ragged_pipeline_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("loco-asr_amd.dp")
+    D, cap, n_rounds = 8, 3, 5
+    g = dp.RaggedGatherPipeline(cap=cap, dim=D)
+    got = {}
+    expect = {}
+    # every rank knows what every rank contributes: unit gid = (round, rank, row), value = gid everywhere
+    gid = 0
+    plan = []
+    for k in range(n_rounds):
+        per_rank = []
+        for r in range(world):
+            n = (k + 2 * r) % (cap + 1)          # 0..3 units, differs by rank and round; rank 1 is EMPTY in round 2 (n = 0 at k=2? (2+2)%4=0)
+            t = 2 + (3 * k + r) % 4             # padded length differs by rank and round
+            units = []
+            for row in range(n):
+                keep = t if (k % 2 == 0) else max(1, t - 1 - row % 2)   # odd rounds: ragged rows per unit (the packed forward's case)
+                units.append((gid, keep))
+                expect[gid] = torch.full((keep, D), float(gid))
+                gid += 1
+            per_rank.append((t, units))
+        plan.append(per_rank)
+    for k in range(n_rounds):
+        t, units = plan[k][rank]
+        if units:
+            local = torch.stack([torch.cat([torch.full((keep, D), float(u)), torch.full((t - keep, D), -7.0)]) for u, keep in units])
+            done = g.submit(local, [u for u, _ in units], [keep for _, keep in units] if k % 2 else None)
+        else:
+            done = g.submit(None, [])
+        if k < 2:
+            assert done == []                     # nothing is waited for in the round that issues it, nor in the next
+        for u, e in done:
+            got[u] = e.clone()
+    for u, e in g.flush():
+        got[u] = e.clone()
+    assert g.collectives == 2 * n_rounds          # one metadata + one payload collective per round
+    assert sorted(got) == sorted(expect), (sorted(got), sorted(expect))
+    for u in expect:
+        assert torch.equal(got[u], expect[u]), u
+    torch.save(got, os.path.join(out_dir, f"pipe{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ragged_gather_pipeline_two_ranks(tmp_path):
+    """extract.py --gather: the overlapped ragged gather -- per round one metadata and one payload collective, both
+    asynchronous, results two rounds later -- with batch sizes, padded lengths and kept rows that differ by rank and by round,
+    including a rank that contributes nothing in a round; every rank ends with the same rows."""
+    mp.spawn(_ragged_pipeline_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "pipe0.pt"), torch.load(tmp_path / "pipe1.pt")
+    assert sorted(a) == sorted(b)
+    for u in a:
+        assert torch.equal(a[u], b[u])

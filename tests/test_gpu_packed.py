@@ -202,3 +202,29 @@ def test_packed_c_abi_error_codes():
         enc.forward_packed([])
     with pytest.raises(ValueError, match="shorter than one encoder frame"):
         enc.forward_packed([dict(input_values=torch.zeros(2, 300))])
+
+
+def test_extract_cli_pack_writes_the_reference_batches_embeddings(tmp_path):
+    """extract.py --pack G: the same files, ids, targets and shapes as the one-batch-at-a-time loop (every utterance keeps the padded
+    frames of ITS OWN batch, not the pack's), embeddings equal to the fp32 summation order of the GEMMs; several windows, a last
+    pack that is short, an odd utterance without a batch mate."""
+    import importlib
+    import os
+    import pickle
+    extract = importlib.import_module("loco-asr_amd.extract")
+    common = ["-m", "audio", "-s", "devel", "--synthetic", "37", "--synthetic-seconds", "2.0", "--random-init"]
+    ref, out = str(tmp_path / "one"), str(tmp_path / "packed")
+    st_a = extract.main(common + ["--out", ref, "--inflight", "1"])
+    st_b = extract.main(common + ["--out", out, "--pack", "4", "--pack-window", "2"])
+    assert st_a["frames"] == st_b["frames"] and st_b["pack"] == 4
+    fa, fb = os.path.join(ref, "devel", "audio"), os.path.join(out, "devel", "audio")
+    names = sorted(os.listdir(fa))
+    assert len(names) == 37 and names == sorted(os.listdir(fb))
+    worst = 0.0
+    for n in names:
+        with open(os.path.join(fa, n), "rb") as f1, open(os.path.join(fb, n), "rb") as f2:
+            a, b = pickle.load(f1), pickle.load(f2)
+        assert a["id"] == b["id"] and a["embedding"].shape == b["embedding"].shape and (a["target"] == b["target"]).all()
+        assert b["embedding"].dtype == np.float32 and b["embedding"].flags["C_CONTIGUOUS"]
+        worst = max(worst, rel_l2(b["embedding"], a["embedding"]))
+    assert worst < PACK_TOL, worst

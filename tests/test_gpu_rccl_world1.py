@@ -99,20 +99,37 @@ def test_head_gradient_all_reduce_over_rccl_at_world_size_one(tmp_path):
 
 def test_extract_gather_over_rccl_at_world_size_one(tmp_path):
     """BASELINE.json configs[3] ("RCCL all-gather of embeddings"): extract.py --gather routes every batch through
-    dp.gather_ragged -- two metadata gathers and the one large all_gather_into_tensor on DEVICE tensors over RCCL -- and rank 0
-    writes what comes out of the collective.  Its pickles must equal, byte for byte, those of the run that never touched a
-    process group."""
+    dp.RaggedGatherPipeline -- per round ONE metadata all-gather and the one large all_gather_into_tensor, both asynchronous on
+    DEVICE tensors over RCCL and waited for a round (two rounds) later -- and rank 0 writes what comes out of the collective.  Its
+    pickles must equal, byte for byte, those of the run that never touched a process group; with --pack the rounds are packs and the
+    gathered rows of a clip end where its own batch ends."""
     script = os.path.join(ROOT, "loco-asr_amd", "extract.py")
     common = ["-m", "audio", "-s", "devel", "--synthetic", "7", "--synthetic-seconds", "1.5", "--random-init"]
     out_a, out_b = str(tmp_path / "plain"), str(tmp_path / "gathered")
     _torchrun(script, common + ["--out", out_a], _launcher_env(), False)
     log = _torchrun(script, common + ["--out", out_b, "--gather"], _launcher_env(), True)
-    assert "Embedding gathers issued: 4 (backend nccl, world size 1)" in log, log[-1500:]  # pairs (0,1) (2,3) (4,5) (6)
+    assert "Embedding gathers issued: 4 rounds, 8 collectives (backend nccl, world size 1)" in log, log[-1500:]  # pairs (0,1) (2,3) (4,5) (6)
     fa, fb = os.path.join(out_a, "devel", "audio"), os.path.join(out_b, "devel", "audio")
     names = sorted(os.listdir(fa))
     assert len(names) == 7 and names == sorted(os.listdir(fb))
     for n in names:
         assert open(os.path.join(fa, n), "rb").read() == open(os.path.join(fb, n), "rb").read(), n
+    # packed rounds: 4 batches in packs of 3 -> 2 rounds; gathered == written directly, byte for byte
+    out_c, out_d = str(tmp_path / "packed"), str(tmp_path / "packed_gathered")
+    _torchrun(script, common + ["--out", out_c, "--pack", "3"], _launcher_env(), False)
+    log = _torchrun(script, common + ["--out", out_d, "--pack", "3", "--gather"], _launcher_env(), True)
+    assert "Embedding gathers issued: 2 rounds, 4 collectives (backend nccl, world size 1)" in log, log[-1500:]
+    fc, fd = os.path.join(out_c, "devel", "audio"), os.path.join(out_d, "devel", "audio")
+    assert names == sorted(os.listdir(fc)) == sorted(os.listdir(fd))
+    import pickle
+    import numpy as np
+    for n in names:
+        assert open(os.path.join(fc, n), "rb").read() == open(os.path.join(fd, n), "rb").read(), n
+        with open(os.path.join(fa, n), "rb") as f1, open(os.path.join(fc, n), "rb") as f2:
+            a, c = pickle.load(f1), pickle.load(f2)
+        assert a["embedding"].shape == c["embedding"].shape and a["id"] == c["id"] and (a["target"] == c["target"]).all()
+        d = np.linalg.norm(a["embedding"].astype(np.float64) - c["embedding"]) / np.linalg.norm(a["embedding"].astype(np.float64))
+        assert d < 5e-6, (n, d)  # a pack differs from the one-batch forward by GEMM summation order only
 
 
 def test_bench_gpus_two_on_a_one_gpu_box_fails_for_lack_of_a_device_not_of_a_launcher():

@@ -43,7 +43,9 @@ print(f"corpus: {N} WAV files of 2-6 s (mean {sum(lens) / N / 16000:.2f} s) in S
 base = ["-m", "audio", "-s", "devel", "--data-path", root, "--random-init", "--loader-threads", "12", "--sink-threads", "8"]
 digests, results = {}, []
 extract.main(["-m", "audio", "-s", "devel", "--synthetic", "32", "--synthetic-seconds", "6", "--random-init", "--out", tempfile.mkdtemp(prefix="cli_warm_", dir=shm)])
-for k in (1, 2, 4, 8):
+ref_dir = None
+KS = (1,) if "--pack-only" in sys.argv else (1, 2, 4, 8)
+for k in KS:
     out = tempfile.mkdtemp(prefix=f"cli_bench_k{k}_", dir=shm)
     st = extract.main(base + ["--out", out, "--inflight", str(k)])
     dt = st["seconds"]  # the loop alone: decode -> batching -> H2D -> encoder -> D2H -> pickles closed (no model load)
@@ -54,14 +56,48 @@ for k in (1, 2, 4, 8):
     for n in names:
         h.update(n.encode()); h.update(open(os.path.join(folder, n), "rb").read())
     digests[k] = (len(names), h.hexdigest())
-    shutil.rmtree(out, ignore_errors=True)
+    if k == 1 and "--no-pack" not in sys.argv:
+        ref_dir = out  # kept: the --pack runs below are compared with it file by file
+    else:
+        shutil.rmtree(out, ignore_errors=True)
     r = dict(inflight=k, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1), files=len(names), sha256=h.hexdigest()[:16])
     results.append(r)
     print(f"--inflight {k}: {N} utterances in {dt:.2f} s (decode, batching, H2D, encoder, D2H, pickles written) = {N / dt:.1f} utterances/s, "
           f"{frames / dt:,.0f} frames/s; {len(names)} pickles, sha256 {h.hexdigest()[:16]}", flush=True)
-shutil.rmtree(root, ignore_errors=True)
 assert len({d for d in digests.values()}) == 1, f"pickles differ between --inflight values: {digests}"
 print("all --inflight values wrote byte-identical pickles")
+# ---- --pack G: G of the SAME reference batches per launch sequence (loco_forward_packed); equal to the runs above up to the fp32
+# summation order of the GEMMs, checked file by file against the --inflight 1 pickles
+if ref_dir is not None:
+    import pickle
+    ref_folder = os.path.join(ref_dir, "devel", "audio")
+    extract.main(["-m", "audio", "-s", "devel", "--synthetic", "256", "--synthetic-seconds", "6", "--synthetic-min-seconds", "2", "--random-init", "--pack", "32",
+                  "--out", tempfile.mkdtemp(prefix="cli_warm_", dir=shm)])
+    for g, k, th, sk in ((8, 2, 12, 8), (16, 2, 12, 8), (32, 2, 12, 8), (64, 2, 12, 8), (32, 2, 16, 12), (32, 3, 16, 12)):
+        out = tempfile.mkdtemp(prefix=f"cli_bench_pack{g}_", dir=shm)
+        st = extract.main(["-m", "audio", "-s", "devel", "--data-path", root, "--random-init", "--loader-threads", str(th), "--sink-threads", str(sk),
+                           "--out", out, "--pack", str(g), "--inflight", str(k)])
+        dt = st["seconds"]
+        assert st["frames"] == frames and st["utterances"] == N, st
+        folder = os.path.join(out, "devel", "audio")
+        names = sorted(os.listdir(folder))
+        assert names == sorted(os.listdir(ref_folder))
+        worst = 0.0
+        for n in names:
+            with open(os.path.join(folder, n), "rb") as fa, open(os.path.join(ref_folder, n), "rb") as fb:
+                a, b = pickle.load(fa), pickle.load(fb)
+            assert a["id"] == b["id"] and a["embedding"].shape == b["embedding"].shape and (a["target"] == b["target"]).all(), n
+            e64 = b["embedding"].astype(np.float64)
+            worst = max(worst, float(np.linalg.norm(a["embedding"] - e64) / np.linalg.norm(e64)))
+        assert worst < 5e-6, worst
+        shutil.rmtree(out, ignore_errors=True)
+        r = dict(pack=g, inflight=k, loader_threads=th, sink_threads=sk, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1),
+                 files=len(names), worst_rel_l2_vs_inflight1=worst)
+        results.append(r)
+        print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
+              f"{len(names)} pickles, worst relative L2 against the --inflight 1 pickles {worst:.2e}", flush=True)
+    shutil.rmtree(ref_dir, ignore_errors=True)
+shutil.rmtree(root, ignore_errors=True)
 print(json.dumps({"corpus": {"utterances": N, "frames_padded": frames, "frames_valid": valid}, "runs": results}))
 if "--big" in sys.argv:
     # the headline shape through the CLI: 768 WAV files of 30 s (SLURP layout, /dev/shm), --batch-size 32 (NOT the reference's batching:
