@@ -187,7 +187,11 @@ int loco_status_check(const void* status, char* buf, size_t buflen);
  *   wav      f32 [B, L] device: clip b in wav[b, 0 .. pad_len[b]) exactly as its own batch would hold it (its samples, then the
  *            zeros of padding="longest"); what lies beyond pad_len[b] is never used
  *   attention_mask  i32 [B, L] device or NULL: as in loco_forward for the first pad_len[b] entries of row b; entries beyond MUST be
- *            0 (the valid-frame count is the row sum).  NULL = every sample below pad_len[b] is present.
+ *            0 (the valid-frame count is the row sum).
+ *   valid_len  int64 [B] HOST or NULL: the row sums of that mask, for callers that know them -- HF reduces the mask to exactly this
+ *            number before anything else (modeling_speecht5.py:569-582: attention_mask.cumsum(-1)[:, -1]), so a mask made by
+ *            padding="longest" carries no other information; 0 <= valid_len[b] <= pad_len[b].  With valid_len no mask crosses
+ *            PCIe and none is counted on the device.  Give one of the two, or neither = every sample below pad_len[b] is present.
  * and per clip b, with T_b = loco_output_frames(pad_len[b]) and T = loco_output_frames(L):
  *   - GroupNorm moments of conv layer 0 over the conv frames of pad_len[b] samples -- the zero tail of its own batch counts,
  *     nothing beyond (the same fp64 partial sums in the same order as a forward of that batch alone);
@@ -203,9 +207,9 @@ int loco_status_check(const void* status, char* buf, size_t buflen);
  * block also stages the per-clip lengths: it must stay untouched -- and should be pinned -- until `stream` has completed the
  * forward).  B <= loco_max_pack_clips(). */
 int loco_max_pack_clips(void);
-int loco_forward_packed(loco_encoder* enc, int precision, const float* wav, const int32_t* attention_mask, int32_t B, int64_t L,
-                        const int64_t* pad_len, float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
-                        size_t workspace_bytes, void* stream, void* status);
+int loco_forward_packed(loco_encoder* enc, int precision, const float* wav, const int32_t* attention_mask, const int64_t* valid_len,
+                        int32_t B, int64_t L, const int64_t* pad_len, float* out, int32_t* out_frames, float* const* hidden_states,
+                        void* workspace, size_t workspace_bytes, void* stream, void* status);
 int loco_status_range(const void* status, int32_t stage, float* amax, int32_t* layer, char* name, size_t namelen);
 
 /* ---- sample-rate conversion to 16 kHz ("next" row f-4) ---------------------------------------------------------------------

@@ -51,7 +51,8 @@ SIGNATURES = {
     "loco_status_bytes": (_sz, []),
     "loco_forward_async": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _i64, _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
     "loco_max_pack_clips": (C.c_int, []),
-    "loco_forward_packed": (C.c_int, [_vp, C.c_int, _vp, _vp, _i32, _i64, C.POINTER(_i64), _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
+    "loco_forward_packed": (C.c_int, [_vp, C.c_int, _vp, _vp, C.POINTER(_i64), _i32, _i64, C.POINTER(_i64), _vp, _vp, C.POINTER(_vp), _vp, _sz, _vp,
+                                      _vp]),
     "loco_status_check": (C.c_int, [_vp, C.c_char_p, _sz]),
     "loco_status_range": (C.c_int, [_vp, _i32, C.POINTER(_f), C.POINTER(_i32), C.c_char_p, _sz]),
     "loco_resample_design": (C.c_int, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),

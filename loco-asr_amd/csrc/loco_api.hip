@@ -97,9 +97,10 @@ struct StatusBlock {
     char msg[384];                            // non-empty: a range verdict known on the host (weights outside the planes' range)
     float words[kRangeMaxStages * kRangeShards];
     // loco_forward_packed: per clip, the conv-layer-0 and the encoder frame counts of its OWN reference batch's padded length
-    // ([0, B): conv0 frames, [B, 2B): encoder frames).  Staged here because the block is host memory the caller keeps alive (and
-    // pinned) until the stream has completed the forward: the source of the host-to-device copy that opens the forward.
-    int32_t clip_tab[2 * kMaxPackClips];
+    // ([0, B): conv0 frames, [B, 2B): encoder frames, [2B, 3B): valid frames when the caller gave valid_len instead of a mask).
+    // Staged here because the block is host memory the caller keeps alive (and pinned) until the stream has completed the forward:
+    // the source of the host-to-device copy that opens the forward.
+    int32_t clip_tab[3 * kMaxPackClips];
 };
 // device side of the same: the first bytes of every workspace
 constexpr size_t kStatusDevBytes = (sizeof(float) * kRangeMaxStages * kRangeShards + 255) & ~size_t(255);
@@ -272,7 +273,7 @@ void carve_plan(const loco_encoder* e, Plan& p) {
         return at;
     };
     p.off_frames = take((size_t)B * sizeof(int32_t));
-    p.off_clip = take((size_t)2 * B * sizeof(int32_t));  // packed forward: per-clip conv0 / encoder frame counts (StatusBlock::clip_tab)
+    p.off_clip = take((size_t)3 * B * sizeof(int32_t));  // packed forward: per-clip conv0 / encoder frame counts (StatusBlock::clip_tab)
     p.off_c0scratch = take(conv0_scratch_bytes(B));
     p.off_a = take((size_t)B * p.Tc[0] * kConvDim * f);
     p.off_b = take((size_t)B * p.Tc[1] * kConvDim * f);
@@ -1134,7 +1135,8 @@ int loco_set_taps(loco_encoder* e, float* conv_stack, float* feature_projection,
 namespace {
 // clip_tab: null, or (loco_forward_packed) the host table {conv0 frames [B], encoder frames [B]} of THIS (half-)batch's clips
 int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
-                float* const* hidden_states, char* ws, hipStream_t s, const int32_t* clip_t0 = nullptr, const int32_t* clip_rows = nullptr) {
+                float* const* hidden_states, char* ws, hipStream_t s, const int32_t* clip_t0 = nullptr, const int32_t* clip_rows = nullptr,
+                const int32_t* clip_valid = nullptr) {
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* bufA = reinterpret_cast<float*>(ws + p.off_a);
     float* bufB = reinterpret_cast<float*>(ws + p.off_b);
@@ -1146,8 +1148,8 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
     float* qp = reinterpret_cast<float*>(ws + p.off_qp);
     float* ffn = reinterpret_cast<float*>(ws + p.off_ffn);
 
-    // ---- valid frame counts (HF :569-598)
-    {
+    // ---- valid frame counts (HF :569-598); a packed forward that was given valid_len has them from the host (below)
+    if (!clip_valid) {
         Bracket br(e, s, K_FRAMES, 0.0, mask ? 4.0 * B * (double)L : 0.0);
         HIP_TRY(launch_frame_counts(mask, B, L, frames, s));
     }
@@ -1162,7 +1164,8 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
         int32_t* tab = reinterpret_cast<int32_t*>(ws + p.off_clip);
         HIP_TRY(hipMemcpyAsync(tab, clip_t0, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(tab + B, clip_rows, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        if (!mask) HIP_TRY(hipMemcpyAsync(frames, tab + B, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (clip_valid) HIP_TRY(hipMemcpyAsync(frames, clip_valid, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        else if (!mask) HIP_TRY(hipMemcpyAsync(frames, tab + B, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         bufs.frames_or_null = frames;
         bufs.t0_clip = tab;
         bufs.rows_clip = tab + B;
@@ -1176,7 +1179,7 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
 // is a single-caller diagnostic mode) and the sinusoid table when a clip longer than any before makes it grow.
 int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* wav, const int32_t* mask, int32_t B, int64_t L, float* out,
                  int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream,
-                 const int64_t* pad_len = nullptr) {
+                 const int64_t* pad_len = nullptr, const int64_t* valid_len = nullptr) {
     if (!e || !wav || !out || !workspace || !st) return fail(LOCO_E_INVALID, "loco_forward: null argument");
     if (!e->finalized) return fail(LOCO_E_STATE, "loco_forward: call loco_finalize_weights first");
     if (!e->speech_ready) return fail(LOCO_E_STATE, "loco_forward: this encoder was loaded without the speech prenet weights");
@@ -1195,7 +1198,7 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_sin_rows(e, (int)p.T + 2, s);
     if (rc) return rc;
-    const int32_t *tab_t0 = nullptr, *tab_rows = nullptr;
+    const int32_t *tab_t0 = nullptr, *tab_rows = nullptr, *tab_valid = nullptr;
     if (pad_len) {  // loco_forward_packed: validate, then derive the two per-clip frame counts into the caller's status block
         if (B > kMaxPackClips) return fail(LOCO_E_INVALID, "loco_forward_packed: %d clips > %d", B, kMaxPackClips);
         for (int b = 0; b < B; ++b) {
@@ -1204,9 +1207,16 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
                             (long long)L);
             st->clip_tab[b] = (int32_t)conv_out_len(pad_len[b], kConvK[0], kConvS[0]);
             st->clip_tab[B + b] = (int32_t)loco_output_frames(pad_len[b]);
+            if (valid_len) {
+                if (valid_len[b] < 0 || valid_len[b] > pad_len[b])
+                    return fail(LOCO_E_INVALID, "loco_forward_packed: valid_len[%d] = %lld must lie in [0, pad_len = %lld]", b,
+                                (long long)valid_len[b], (long long)pad_len[b]);
+                st->clip_tab[2 * B + b] = (int32_t)loco_output_frames(valid_len[b]);  // as frames_from_counts_kernel: HF's floor division
+            }
         }
         tab_t0 = st->clip_tab;
         tab_rows = st->clip_tab + B;
+        if (valid_len) tab_valid = st->clip_tab + 2 * B;
     }
     Call c;
     c.precision = precision;
@@ -1215,7 +1225,7 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
     if ((rc = range_begin(e, c, s))) return rc;
     if (!dual) {
-        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s, tab_t0, tab_rows);
+        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s, tab_t0, tab_rows, tab_valid);
         if (rc) return rc;
         return range_end(c, s);
     }
@@ -1233,13 +1243,13 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
     // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
     c.dual = true;
-    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s, tab_t0, tab_rows);
+    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s, tab_t0, tab_rows, tab_valid);
     int rc1 = LOCO_OK;
     std::string first_error;
     if (rc) first_error = g_err;
     else rc1 = forward_one(e, c, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
                            out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side, tab_t0 ? tab_t0 + B0 : nullptr,
-                           tab_rows ? tab_rows + B0 : nullptr);
+                           tab_rows ? tab_rows + B0 : nullptr, tab_valid ? tab_valid + B0 : nullptr);
     c.dual = false;
     if (!rc && rc1) first_error = g_err;
     const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves
@@ -1334,17 +1344,18 @@ int loco_forward_async(loco_encoder* e, int precision, const float* wav, const i
     return rc;
 }
 
-int loco_forward_packed(loco_encoder* e, int precision, const float* wav, const int32_t* mask, int32_t B, int64_t L, const int64_t* pad_len,
-                        float* out, int32_t* out_frames, float* const* hidden_states, void* workspace, size_t workspace_bytes, void* stream,
-                        void* status) {
+int loco_forward_packed(loco_encoder* e, int precision, const float* wav, const int32_t* mask, const int64_t* valid_len, int32_t B, int64_t L,
+                        const int64_t* pad_len, float* out, int32_t* out_frames, float* const* hidden_states, void* workspace,
+                        size_t workspace_bytes, void* stream, void* status) {
     if (!e || !status || !pad_len) return fail(LOCO_E_INVALID, "loco_forward_packed: null argument");
+    if (mask && valid_len) return fail(LOCO_E_INVALID, "loco_forward_packed: give attention_mask or valid_len, not both");
     if (precision != -1 && !loco_precision_name(precision))
         return fail(LOCO_E_INVALID, "loco_forward_packed: precision must be -1 (the handle's mode) or one of " LOCO_PRECISION_MODES);
     if (reinterpret_cast<uintptr_t>(status) & 7) return fail(LOCO_E_INVALID, "loco_forward_packed: the status block must be 8-byte aligned");
     StatusBlock* st = reinterpret_cast<StatusBlock*>(status);
     st->magic = 0;
     const int rc = forward_impl(e, precision < 0 ? e->precision : precision, st, wav, mask, B, L, out, out_frames, hidden_states, workspace,
-                                workspace_bytes, stream, pad_len);
+                                workspace_bytes, stream, pad_len, valid_len);
     if (rc) st->magic = 0;
     return rc;
 }

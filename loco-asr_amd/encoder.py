@@ -21,7 +21,9 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import threading
+import time
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -33,6 +35,16 @@ from .synth import (CONV_DIM, CONV_KERNEL, FFN, HEAD_DIM, HEADS, HIDDEN, LAYERS,
 
 PAD_TOKEN_ID = 1
 MAX_SPEECH_POSITIONS = 4000
+
+
+@dataclass
+class Pack:
+    """Several reference batches laid out as one [B, L] problem (``pack_batches``; include/loco_asr.h, loco_forward_packed)."""
+    wav: torch.Tensor                       # f32 [B, L] device
+    mask: Optional[torch.Tensor]            # i32 [B, L] device, or None when valid_len is given / every sample is present
+    valid_len: Optional[list]               # per clip: present samples (the row sums of the batches' masks), or None
+    pad_len: list                           # per clip: padded length of its own batch
+    spans: list                             # per batch: (first clip, clips, output frames)
 
 
 @dataclass
@@ -173,12 +185,13 @@ class ForwardTicket:
     it is stored, the ticket is marked resolved and its slot released either way, and only ``result()`` of this ticket raises it
     -- the slot's next forward, ``drain()`` and ``set_inflight()`` settle the ticket without re-raising somebody else's error."""
 
-    def __init__(self, enc, slot, x, m, out, frames, precision, pad_len=None, spans=None):
+    def __init__(self, enc, slot, x, m, out, frames, precision, pack=None):
         self._enc, self._slot = enc, slot
         self._x, self._m = x, m  # kept alive until the forward has consumed them
         self._out, self._frames = out, frames
         self._precision = precision
-        self._pad_len, self._spans = pad_len, spans  # packed forward: per-clip padded lengths, (first clip, clips, frames) per batch
+        self._pack = pack  # packed forward: per-clip lengths and per-batch spans
+        self._spans = pack.spans if pack is not None else None
         self._done = torch.cuda.Event()
         self._resolved = False
         self._error = None
@@ -221,7 +234,7 @@ class ForwardTicket:
                 rc = enc._lib.loco_status_check(C.c_void_p(slot.status.data_ptr()), None, 0)
                 if rc == -5 and enc.range_policy == "fp32":
                     with torch.cuda.device(self._out.device), torch.cuda.stream(slot.stream):
-                        extra = () if self._pad_len is None else (self._pad_len,)
+                        extra = () if self._pack is None else (self._pack,)
                         enc._enqueue(slot, self._x, self._m, self._out, self._frames, "f32", *extra)
                         slot.stream.synchronize()
                     self.used_fp32 = True
@@ -289,6 +302,8 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         # forwards in flight (forward_async): slots of (stream, workspace, status block), used round-robin
         self._slots = []
         self._next_slot = 0
+        self._workspace_floor = 0
+        self.submit_profile = {} if os.environ.get("LOCO_EXTRACT_PROFILE") == "1" else None
         self.eval()
 
     # -- lifetime ----------------------------------------------------------------------------------------
@@ -412,21 +427,34 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             if slot.ticket is not None:
                 slot.ticket.settle()
 
-    def _enqueue(self, slot, x, m, out, frames, precision, pad_len=None):
+    def reserve_workspace(self, batch: int, samples: int):
+        """Size the in-flight slots' workspaces for a [batch, samples] problem at their next (re)allocation: a caller that knows
+        its largest batch (extract.py --pack: the longest pack of a sorted window) avoids growing a multi-GB workspace step by
+        step -- every step is a hipMalloc of the new size, and hipFree of the old one synchronises the device."""
+        self._ensure_handle(self._device())
+        self._workspace_floor = max(self._workspace_floor, int(self._lib.loco_workspace_bytes(self._handle, batch, samples)))
+
+    def _enqueue(self, slot, x, m, out, frames, precision, pack=None):
         B, L = x.shape
         need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
         if slot.workspace is None or slot.workspace.numel() < need:
+            t0 = time.perf_counter()
             slot.workspace = None
-            slot.workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+            # grown with headroom: packs of a length-sorted window ask for a little more each time
+            slot.workspace = torch.empty(max(need + need // 4, self._workspace_floor), dtype=torch.uint8, device=x.device)
+            if self.submit_profile is not None:
+                self.submit_profile["workspace (re)allocations"] = self.submit_profile.get("workspace (re)allocations", 0.0) + 1.0
+                self.submit_profile["workspace allocation, s"] = self.submit_profile.get("workspace allocation, s", 0.0) + time.perf_counter() - t0
         mp = C.c_void_p(m.data_ptr()) if m is not None else None
-        if pad_len is None:
+        if pack is None:
             _lib.check(self._lib.loco_forward_async(
                 self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, B, L, C.c_void_p(out.data_ptr()),
                 C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()), slot.workspace.numel(),
                 C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_async")
         else:
+            vl = (C.c_int64 * B)(*pack.valid_len) if pack.valid_len is not None else None
             _lib.check(self._lib.loco_forward_packed(
-                self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, B, L, (C.c_int64 * B)(*pad_len),
+                self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, vl, B, L, (C.c_int64 * B)(*pack.pad_len),
                 C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()),
                 slot.workspace.numel(), C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_packed")
 
@@ -461,41 +489,58 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
         return self._submit(x, m, T)
 
-    def _submit(self, x, m, T, pad_len=None, spans=None):
+    def _submit(self, x, m, T, pack=None):
         """Enqueue one (plain or packed) forward on the next slot.  ``out`` / ``frames`` are allocated on the CALLER's current
         stream (the slot's stream is ordered behind it before the forward, and the caller's stream behind the forward's completion
         event is what ``result()`` provides on the host): a consumer that uses them on its own stream after ``result()`` needs no
         ``record_stream`` for the allocator's sake -- the block returns to the stream it came from."""
         device = x.device
         B = x.shape[0]
+        prof = self.submit_profile  # None, or seconds per phase (LOCO_EXTRACT_PROFILE=1: where a slow enqueue spends its time)
+        t0 = time.perf_counter() if prof is not None else 0.0
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % len(self._slots)
         if slot.ticket is not None:
             slot.ticket.settle()
+        t1 = time.perf_counter() if prof is not None else 0.0
         with torch.cuda.device(device):
             self._sync_weights(device, T + 2)  # also grows the sinusoid table BEFORE anything is in flight on a longer clip
             _lib.check(self._lib.loco_set_streams(self._handle, int(self.streams)), "set_streams")
             cur = torch.cuda.current_stream(device)
-            out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
+            n_out = B * T * HIDDEN
+            if pack is not None:
+                # packs differ in size from one to the next: a request rounded up to 16 MB finds a cached block of the allocator far
+                # more often than an exact one (a miss is a hipMalloc of tens of MB on the enqueuing thread)
+                out = torch.empty(((n_out + (1 << 22) - 1) >> 22) << 22, dtype=torch.float32, device=device)[:n_out].view(B, T, HIDDEN)
+            else:
+                out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
             frames = torch.empty((B,), dtype=torch.int32, device=device)
             slot.stream.wait_stream(cur)
             with torch.cuda.stream(slot.stream):
                 for t in (x, m, out, frames):
                     if t is not None:
                         t.record_stream(slot.stream)
-                ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision, pad_len, spans)
-                self._enqueue(slot, x, m, out, frames, self.precision, pad_len)
+                ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision, pack)
+                t2 = time.perf_counter() if prof is not None else 0.0
+                self._enqueue(slot, x, m, out, frames, self.precision, pack)
+                t3 = time.perf_counter() if prof is not None else 0.0
                 ticket._done.record(slot.stream)
         slot.ticket = ticket
+        if prof is not None:
+            for k_, v_ in (("wait for the slot's previous forward", t1 - t0), ("allocate outputs, order streams", t2 - t1),
+                           ("workspace + enqueue (C ABI)", t3 - t2), ("forwards", 1.0)):
+                prof[k_] = prof.get(k_, 0.0) + v_
         return ticket
 
     # -- packed forward: several reference batches in one launch sequence (include/loco_asr.h, loco_forward_packed) ------------
-    def pack_batches(self, batches, device=None):
+    def pack_batches(self, batches, device=None) -> Pack:
         """Lay the clips of several reference batches out as ONE [B, L] problem: ``batches`` is a list of mappings with
         ``input_values`` f32 [B_i, L_i] and optionally ``attention_mask`` [B_i, L_i] (what SpeechT5FeatureExtractor returns per
-        batch, …base…py:60), on the host or on the device.  Returns (wav [B, L], mask [B, L] or None, pad_len, spans) where clip b
-        keeps the padded length of its own batch (pad_len[b] = L_i) and spans[i] = (first clip, B_i, output frames of batch i).
-        Host inputs are packed in pinned memory and cross PCIe as one copy."""
+        batch, …base…py:60), on the host or on the device.  Clip b keeps the padded length of its own batch (pad_len[b] = L_i);
+        spans[i] = (first clip, B_i, output frames of batch i).  Host batches are packed in pinned memory and cross PCIe as one
+        copy; their masks are reduced on the host to what HF reduces them to anyway -- the number of present samples per clip
+        (modeling_speecht5.py:569-582) -- so no mask is shipped or counted on the device.  Device batches are packed by device-side
+        copies and keep their masks."""
         if not batches:
             raise ValueError("pack_batches: no batches")
         device = device or self._device()
@@ -508,11 +553,13 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
                 raise ValueError(f"attention_mask {tuple(mk.shape)} does not match input_values {tuple(x.shape)}")
         B = sum(int(x.shape[0]) for x in xs)
         L = max(int(x.shape[1]) for x in xs)
-        L = (L + 7) // 8 * 8  # rows start 16-byte aligned: the mask counter's vector path
-        on_host = all(not x.is_cuda for x in xs)
+        L = (L + 7) // 8 * 8  # rows start 16-byte aligned
+        on_host = all(not x.is_cuda for x in xs) and all(mk is None or not mk.is_cuda for mk in ms)
         kw = dict(pin_memory=True) if on_host else dict(device=device)
         wav = torch.zeros((B, L), dtype=torch.float32, **kw)
-        mask = torch.zeros((B, L), dtype=torch.int32, **kw) if any(mk is not None for mk in ms) else None
+        any_mask = any(mk is not None for mk in ms)
+        mask = torch.zeros((B, L), dtype=torch.int32, device=device) if (any_mask and not on_host) else None
+        valid_len = [] if (any_mask and on_host) else None
         pad_len, spans, b0 = [], [], 0
         for x, mk in zip(xs, ms):
             nb, li = int(x.shape[0]), int(x.shape[1])
@@ -525,21 +572,22 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
                     mask[b0:b0 + nb, :li] = mk
                 else:
                     mask[b0:b0 + nb, :li] = 1
+            elif valid_len is not None:
+                valid_len += [int(v) for v in mk.sum(dim=1).tolist()] if mk is not None else [li] * nb
             pad_len += [li] * nb
             spans.append((b0, nb, t))
             b0 += nb
         if on_host:
             wav = wav.to(device, non_blocking=True)
-            mask = mask.to(device, non_blocking=True) if mask is not None else None
-        return wav, mask, pad_len, spans
+        return Pack(wav=wav, mask=mask, valid_len=valid_len, pad_len=pad_len, spans=spans)
 
     @torch.no_grad()
-    def forward_packed_async(self, batches=None, *, packed=None) -> ForwardTicket:
-        """Enqueue the reference batches in ``batches`` (see pack_batches) -- or an already packed ``(wav, mask, pad_len, spans)``
-        -- as one launch sequence; ``ticket.result()`` is a list with one BaseModelOutput per batch whose ``last_hidden_state``
-        [B_i, T_i, 768] (a view into the pack's output) is what ``forward`` returns for that batch alone up to the fp32 summation
-        order of the GEMMs (<= 5e-6 relative L2).  The batches are NOT merged: GroupNorm statistics, the positional conv's zero
-        padding, sinusoid positions and the key mask all follow each clip's own batch (include/loco_asr.h)."""
+    def forward_packed_async(self, batches=None, *, packed: Optional[Pack] = None) -> ForwardTicket:
+        """Enqueue the reference batches in ``batches`` (see pack_batches) -- or an already packed ``Pack`` -- as one launch
+        sequence; ``ticket.result()`` is a list with one BaseModelOutput per batch whose ``last_hidden_state`` [B_i, T_i, 768] (a
+        view into the pack's output) is what ``forward`` returns for that batch alone up to the fp32 summation order of the GEMMs
+        (<= 5e-6 relative L2).  The batches are NOT merged: GroupNorm statistics, the positional conv's zero padding, sinusoid
+        positions and the key mask all follow each clip's own batch (include/loco_asr.h)."""
         if self.training:
             raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
         device = self._device()
@@ -548,15 +596,16 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             self.drain()
         if not self._slots:
             self.set_inflight(2)
-        wav, mask, pad_len, spans = packed if packed is not None else self.pack_batches(batches, device)
-        if wav.device != device:
-            raise RuntimeError(f"module parameters are on {device} but the pack on {wav.device}")
-        if len(pad_len) != wav.shape[0]:
-            raise ValueError("pad_len must hold one entry per clip of the pack")
-        if wav.shape[0] > int(self._lib.loco_max_pack_clips()):
+        pk = packed if packed is not None else self.pack_batches(batches, device)
+        if pk.wav.device != device:
+            raise RuntimeError(f"module parameters are on {device} but the pack on {pk.wav.device}")
+        B = pk.wav.shape[0]
+        if len(pk.pad_len) != B or (pk.valid_len is not None and len(pk.valid_len) != B):
+            raise ValueError("pad_len / valid_len must hold one entry per clip of the pack")
+        if B > int(self._lib.loco_max_pack_clips()):
             raise ValueError(f"a pack holds at most {int(self._lib.loco_max_pack_clips())} clips")
-        T = int(self._lib.loco_output_frames(wav.shape[1]))
-        return self._submit(wav, mask, T, [int(v) for v in pad_len], list(spans))
+        T = int(self._lib.loco_output_frames(pk.wav.shape[1]))
+        return self._submit(pk.wav, pk.mask, T, pk)
 
     def forward_packed(self, batches=None, *, packed=None):
         """``forward_packed_async(...).result()``: list of per-batch outputs."""

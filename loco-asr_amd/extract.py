@@ -59,22 +59,73 @@ def read_slurp_split(data_path: str, split: str):
     return items
 
 
+_soundfile = None  # module, or False once its import has failed (a failed import is re-tried -- and re-paid -- on every call otherwise)
+
+
+def read_pcm_wav(path: str):
+    """(rate, float32 mono samples in [-1, 1)) of an uncompressed RIFF/WAVE file -- 16 / 32-bit PCM or 32-bit float, the formats
+    SLURP's .wav files and this repo's synthetic corpora use -- or None for anything else (the caller falls back to scipy).
+    One read, one frombuffer, one scaling pass: the loader threads share the interpreter lock with the thread that feeds the GPU,
+    so the Python spent per file matters more than the bytes."""
+    import struct
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    if len(raw) < 44 or raw[:4] != b"RIFF" or raw[8:12] != b"WAVE":
+        return None
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(raw):
+        cid, size = raw[pos:pos + 4], struct.unpack_from("<I", raw, pos + 4)[0]
+        if cid == b"fmt ":
+            fmt = struct.unpack_from("<HHIIHH", raw, pos + 8)
+        elif cid == b"data":
+            data = (pos + 8, min(size, len(raw) - pos - 8))
+            break
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        return None
+    tag, channels, rate, _, _, bits = fmt
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(raw, dtype="<i2", count=data[1] // 2, offset=data[0]).astype(np.float32)
+        x *= np.float32(1.0 / 32768.0)
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(raw, dtype="<i4", count=data[1] // 4, offset=data[0]).astype(np.float32)
+        x *= np.float32(1.0 / 2147483648.0)
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(raw, dtype="<f4", count=data[1] // 4, offset=data[0]).astype(np.float32)
+    else:
+        return None
+    if channels > 1:
+        x = x[:x.size // channels * channels].reshape(-1, channels).mean(axis=1)
+    return int(rate), x
+
+
 def load_audio_16k(path: str, device=None):
     """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56): files at another rate (Fisher:
     8 kHz, podcasts: 44.1 kHz) are converted ON THE DEVICE by loco_op_resample (resample.py) and come back as CUDA tensors,
     which the feature extractor pads on the device; 16 kHz files stay numpy arrays on the host.  `device` = the rank's GPU: this
     runs on loader threads, where torch.cuda.current_device() is 0 whatever the main thread selected."""
-    try:
-        import soundfile as sf
-        x, sr = sf.read(path, dtype="float32", always_2d=True)
+    global _soundfile
+    if _soundfile is None:
+        try:
+            import soundfile
+            _soundfile = soundfile
+        except ImportError:
+            _soundfile = False
+    got = read_pcm_wav(path) if path.lower().endswith(".wav") else None
+    if got is not None:
+        sr, x = got
+    elif _soundfile:
+        x, sr = _soundfile.read(path, dtype="float32", always_2d=True)
         x = x.mean(axis=1)
-    except ImportError:
+    else:
         from scipy.io import wavfile
         if not path.lower().endswith(".wav"):
             raise RuntimeError(f"cannot decode {path}: install soundfile for FLAC, or convert to WAV")
         sr, x = wavfile.read(path)
         if x.dtype.kind == "i":
             x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+        elif x.dtype.kind == "u":  # 8-bit PCM is unsigned
+            x = (x.astype(np.float32) - 128.0) / 128.0
         x = x.astype(np.float32)
         if x.ndim == 2:
             x = x.mean(axis=1)
@@ -218,6 +269,10 @@ def main(argv=None):
     ap.add_argument("--pack-window", type=int, default=8,
                     help="with --pack: batches are sorted by padded length inside windows of this many packs before they are packed "
                          "(which batches share a pack does not change any embedding; short batches just do not idle in long packs)")
+    ap.add_argument("--gil-switch-ms", type=float, default=0.5,
+                    help="sys.setswitchinterval for the run, in ms (CPython's default is 5): the thread that enqueues forwards gives the "
+                         "interpreter lock up at every library call and, with a dozen loader / writer threads runnable, waits a switch "
+                         "interval per thread to get it back; 0 = leave the interpreter's setting alone")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
@@ -225,6 +280,8 @@ def main(argv=None):
     if args.modality == "text" and (args.window_seconds > 0 or args.gather):
         raise SystemExit("-m text: --window-seconds / --gather apply to audio only")
 
+    if args.gil_switch_ms > 0:
+        sys.setswitchinterval(args.gil_switch_ms / 1000.0)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -306,11 +363,12 @@ def main(argv=None):
         n_rounds = dp.rounds(len(items), args.batch_size, world)  # equal on all ranks: collectives line up
 
     pack, pack_window = max(0, args.pack), max(1, args.pack_window)
+    if pack:
+        processor.pin_memory = False  # batches are copied into the pack's pinned buffer: their own staging need not be pinned
     if pack and args.bucket_by_length:
         raise SystemExit("--pack keeps the reference's batches (it packs WHOLE batches); --bucket-by-length re-forms them: use one or the other")
     # --pack G: a "round" is one pack of up to G of this rank's batches; equal on all ranks, so that collectives line up
     n_packs = (n_rounds + pack - 1) // pack if pack else 0
-    n_tasks = (n_packs + pack_window - 1) // pack_window if pack else n_rounds
 
     def host_features(idx):
         """decode / synthesise the clips of ONE reference batch, pad and mask them (SpeechT5FeatureExtractor, …base…py:51-65)"""
@@ -331,23 +389,80 @@ def main(argv=None):
         # enqueues forwards only waits for the future; forward_async orders its stream behind the default stream
         return [(idx, host_features(idx).to(device))]
 
-    def host_window(w):
-        """--pack: the host side of one WINDOW of pack_window packs.  The window's reference batches are decoded and padded one by
-        one -- each stays the batch the reference forms -- then sorted by padded length and cut into packs of G (any set of
-        batches may share a pack, include/loco_asr.h: sorting only removes the rows a short batch would idle in a long pack);
-        each pack is laid out in pinned memory and crosses PCIe as one copy (encoder.pack_batches)."""
-        p0, p1 = w * pack_window, min(n_packs, (w + 1) * pack_window)
-        mine = my_batches[p0 * pack:p1 * pack]  # may be short or empty on a rank that has run out
-        feats = [host_features(idx) for idx in mine]
-        if getattr(processor, "normalize_on_device", False):
-            feats = [f.to(device) for f in feats]  # the deferred normaliser runs per BATCH, before batches are packed
-        order = sorted(range(len(mine)), key=lambda i: (int(feats[i]["input_values"].shape[1]), i))
-        out = []
-        for g0 in range(0, len(order), pack):
-            sel = order[g0:g0 + pack]
-            out.append(([mine[i] for i in sel], encoder.pack_batches([feats[i] for i in sel], device)))
-        out += [([], None)] * ((p1 - p0) - len(out))  # empty contributions keep the collectives lined up
-        return out
+    fused_pack = not (args.do_normalize and args.normalize_on_device)
+
+    def host_feats_for_pack(idx):
+        """one reference batch for the pack stage: its decoded clips (host arrays: padded and packed in one go by
+        processor.pack_clips), or -- some clip was resampled on the device, or the normaliser is deferred to the device -- the
+        batch as the processor forms it"""
+        clips = [fetch(i) for i in idx]
+        if fused_pack and not any(torch.is_tensor(c) for c in clips):
+            return clips
+        if any(torch.is_tensor(c) for c in clips):
+            clips = [c if torch.is_tensor(c) else torch.from_numpy(np.ascontiguousarray(c)).to(device) for c in clips]
+        f = processor(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        # the deferred normaliser (--normalize-on-device) runs per BATCH, before batches are packed
+        return f.to(device) if getattr(processor, "normalize_on_device", False) else f
+
+    def batch_len(f):
+        return max(len(c) for c in f) if isinstance(f, list) else int(f["input_values"].shape[1])
+
+    def batch_clips(f):
+        return len(f) if isinstance(f, list) else int(f["input_values"].shape[0])
+
+    def make_pack(fs):
+        if all(isinstance(f, list) for f in fs):
+            return processor.pack_clips(fs, device, encoder._lib.loco_output_frames)
+        fs = [processor(audio=f, sampling_rate=16000, return_tensors="pt", padding="longest") if isinstance(f, list) else f for f in fs]
+        return encoder.pack_batches(fs, device)
+
+    def staged_packs():
+        """--pack: (list of unit-index lists, packed tensors) per pack, in order.  Three host stages run ahead of the GPU:
+        (1) every reference batch is decoded, padded and masked BY ITSELF on the loader pool (it stays the batch the reference
+        forms), two windows ahead; (2) when a window of pack_window packs has all its batches, they are sorted by padded length
+        and cut into packs of G -- any set of batches may share a pack (include/loco_asr.h), sorting only removes the rows a
+        short batch would idle in a long pack; (3) each pack is laid out in pinned memory and crosses PCIe as one copy
+        (encoder.pack_batches) on a small pool of its own, so that it does not queue behind the decoding of later windows."""
+        # windows of 1, 2, 4, ... pack_window packs: the first pack can leave as soon as ITS batches are decoded (a sorted window
+        # cannot be cut before its last batch is in), the steady state sorts over pack_window packs
+        bounds, p0, size = [], 0, 1
+        while p0 < n_packs:
+            bounds.append((p0, min(n_packs, p0 + size)))
+            p0 += size
+            size = min(pack_window, 2 * size)
+        futs, submitted = {}, 0
+        for w, (p0, p1) in enumerate(bounds):
+            ahead_to = bounds[min(len(bounds) - 1, w + 2)][1] * pack  # decoding runs two windows ahead
+            while pool and submitted < min(ahead_to, len(my_batches)):
+                futs[submitted] = pool.submit(host_feats_for_pack, my_batches[submitted])
+                submitted += 1
+            lo, hi = min(len(my_batches), p0 * pack), min(len(my_batches), p1 * pack)
+            feats = {i: (futs.pop(i).result() if pool else host_feats_for_pack(my_batches[i])) for i in range(lo, hi)}
+            order = sorted(range(lo, hi), key=lambda i: (batch_len(feats[i]), i))
+            if order:  # the window's largest pack sizes the slots' workspaces at their next (re)allocation
+                encoder.reserve_workspace(sum(batch_clips(feats[i]) for i in order[-pack:]), batch_len(feats[order[-1]]) + 8)
+            jobs = []
+            for g0 in range(0, len(order), pack):
+                sel = order[g0:g0 + pack]
+                meta, fs = [my_batches[i] for i in sel], [feats[i] for i in sel]
+                jobs.append((meta, pack_pool.submit(make_pack, fs) if pack_pool else fs))
+            feats = None
+            for meta, job in jobs:
+                yield meta, (job.result() if pack_pool else make_pack(job))
+            for _ in range((p1 - p0) - len(jobs)):
+                yield [], None  # this rank has run out of batches: empty contributions keep the collectives lined up
+
+    def staged_batches():
+        ahead = max(2, 2 * inflight, n_loaders)  # batches being prepared while others are on the GPU
+        pending = [pool.submit(host_batch, r) for r in range(min(ahead, n_rounds))] if pool else []
+        for rnd in range(n_rounds):
+            if pool:
+                work = pending.pop(0).result()
+                if rnd + ahead < n_rounds:
+                    pending.append(pool.submit(host_batch, rnd + ahead))
+            else:
+                work = host_batch(rnd)
+            yield from work
 
     def on_device(_device=device):  # loader threads start on GPU 0: select the rank's GPU for anything they do there
         torch.cuda.set_device(_device)
@@ -358,9 +473,7 @@ def main(argv=None):
     n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
     pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None
     clip_pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 1 and args.batch_size >= 8 and args.window_seconds <= 0 else None
-    host_task = host_window if pack else host_batch
-    ahead = max(2, n_loaders) if pack else max(2, 2 * inflight, n_loaders)  # tasks being prepared while others are on the GPU
-    pending = [pool.submit(host_task, r) for r in range(min(ahead, n_tasks))] if pool else []
+    pack_pool = ThreadPoolExecutor(min(4, n_loaders), initializer=on_device) if pack and n_loaders > 0 else None
     encoder = model.speecht5.encoder
     if inflight > 1 or pack:
         encoder.set_inflight(max(1, inflight))
@@ -376,6 +489,7 @@ def main(argv=None):
         """What follows a forward: the optional gather, then the sink -- in order, whatever finished first.  meta = the unit
         indices of one batch, or (--pack) the list of such lists of one pack; res = BaseModelOutput / ticket / None."""
         nonlocal gathers, frames_done
+        t_f0 = time.perf_counter()
         if pack:
             if res is not None:
                 res.result()
@@ -390,16 +504,20 @@ def main(argv=None):
             emb, idx, rows = (out.last_hidden_state if out is not None else None), meta, None
             if emb is not None:
                 frames_done += int(emb.shape[0]) * int(emb.shape[1])
+        t_f1 = time.perf_counter()
         if gatherer is not None:
             write_gathered(gatherer.submit(emb, idx, rows, device))  # two collectives per round, both overlapped (dp.py)
             gathers += 1
         elif idx:
             sink.submit([items[i][0] for i in idx], emb, encode_labels([items[i][4] for i in idx]), rows=rows, chunk=8 if pack else 0)
+        cprof[0] += t_f1 - t_f0
+        cprof[1] += time.perf_counter() - t_f1
 
     import queue
     import threading
     import time
     frames_done = 0
+    cprof = [0.0, 0.0]  # consumer side, seconds: waiting for forwards (+ range check), handing results to the gather / the sink
     torch.cuda.synchronize(device)
     t_loop = time.perf_counter()
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format, workers=args.sink_threads,
@@ -430,40 +548,38 @@ def main(argv=None):
         try:
             prof = [0.0] * 4 if os.environ.get("LOCO_EXTRACT_PROFILE") == "1" else None  # seconds: wait for the staged batch, H2D, enqueue, hand-over
             tick = time.perf_counter
-            for rnd in range(n_tasks):
-                if failure:
-                    break
+            stream_ = staged_packs() if pack else staged_batches()
+            while not failure:
                 t_a = tick()
-                if pool:
-                    work = pending.pop(0).result()
-                    if rnd + ahead < n_tasks:
-                        pending.append(pool.submit(host_task, rnd + ahead))
-                else:
-                    work = host_task(rnd)
+                try:
+                    meta, feats = next(stream_)
+                except StopIteration:
+                    break
                 t_b = tick()
-                for meta, feats in work:
-                    t_b2 = tick()
-                    if feats is None:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
-                        item = (meta, None)
-                        t_c = t_b2
-                    elif pack:
-                        t_c = t_b2
-                        item = (meta, encoder.forward_packed_async(packed=feats))
-                    else:
-                        on_dev = feats if feats["input_values"].is_cuda else feats.to(device)
-                        t_c = tick()
-                        item = (meta, encoder.forward_async(**on_dev) if inflight > 1 else encoder(**on_dev))
-                    t_d = tick()
-                    if consumer:
-                        todo.put(item)
-                    else:
-                        finish(*item)
-                    if prof is not None:
-                        t_e = tick()
-                        for k_, v_ in enumerate((t_b - t_a, t_c - t_b2, t_d - t_c, t_e - t_d)):
-                            prof[k_] += v_
-                        t_a = t_b  # the wait is charged to the task's first item only
+                if feats is None:  # this rank has run out of batches: an empty contribution keeps the collectives lined up
+                    item = (meta, None)
+                    t_c = t_b
+                elif pack:
+                    t_c = t_b
+                    item = (meta, encoder.forward_packed_async(packed=feats))
+                else:
+                    on_dev = feats if feats["input_values"].is_cuda else feats.to(device)
+                    t_c = tick()
+                    item = (meta, encoder.forward_async(**on_dev) if inflight > 1 else encoder(**on_dev))
+                t_d = tick()
+                if consumer:
+                    todo.put(item)
+                else:
+                    finish(*item)
+                if prof is not None:
+                    t_e = tick()
+                    for k_, v_ in enumerate((t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d)):
+                        prof[k_] += v_
             if prof is not None:
+                t_close = tick()
+                print("consumer thread so far, s: waiting for forwards %.3f, gather / sink hand-over %.3f; loop so far %.3f s" % (cprof[0], cprof[1], t_close - t_loop))
+                if getattr(encoder, "submit_profile", None):
+                    print("inside forward_async / forward_packed_async, s:", {k_: round(v_, 4) for k_, v_ in encoder.submit_profile.items()})
                 print("main thread, ms per %s: wait for the staged batch %.3f, H2D %.3f, enqueue %.3f, hand-over / finish %.3f"
                       % (("pack" if pack else "batch",) + tuple(1e3 * v_ / max(1, n_packs if pack else n_rounds) for v_ in prof)))
         finally:
@@ -493,7 +609,7 @@ def main(argv=None):
         import torch.distributed as dist
         print(f"Embedding gathers issued: {gathers} rounds, {gatherer.collectives} collectives (backend {dist.get_backend()}, world size {world})")
         stats["gather_rounds"], stats["collectives"] = gathers, gatherer.collectives
-    for ex in (pool, clip_pool):
+    for ex in (pool, clip_pool, pack_pool):
         if ex is not None:
             ex.shutdown()
     print("Done!")

@@ -96,6 +96,44 @@ class SpeechT5FeatureExtractorMI355X:
             out["attention_mask"] = m
         return out
 
+    def pack_clips(self, batches, device, output_frames):
+        """The fused form of ``[self(audio=b, padding="longest") for b in batches]`` + ``encoder.pack_batches`` for clips that live
+        on the host: every batch is padded to ITS OWN longest clip exactly as ``__call__`` pads it (zeros = padding_value 0 only;
+        the attention mask of padding="longest" is "ones up to the clip's length", carried as valid_len -- HF reduces the mask to
+        that number anyway, modeling_speecht5.py:569-582; do_normalize per clip over its unpadded samples), but the clips are
+        written ONCE, straight into the pack's pinned [B, L] buffer, instead of into a per-batch tensor and from there into the
+        pack.  ``batches`` = list of lists of 1-D float arrays; ``output_frames`` = loco_output_frames.  Returns encoder.Pack."""
+        from .encoder import Pack
+        if float(self.padding_value) != 0.0:
+            raise ValueError("pack_clips pads with zeros (the reference's processor default); use __call__ + pack_batches otherwise")
+        if self.do_normalize and self.normalize_on_device:
+            raise ValueError("pack_clips normalises on the host; use __call__ + pack_batches for normalize_on_device")
+        groups = [[np.asarray(c, dtype=np.float32).reshape(-1) for c in b] for b in batches]
+        if not groups or any(not g for g in groups):
+            raise ValueError("empty batch")
+        if self.do_normalize:
+            groups = [[self.zero_mean_unit_var_norm(c) for c in g] for g in groups]
+        B = sum(len(g) for g in groups)
+        lens = [max(len(c) for c in g) for g in groups]
+        L = (max(lens) + 7) // 8 * 8
+        wav = torch.empty((B, L), dtype=torch.float32, pin_memory=bool(torch.cuda.is_available()))
+        w = wav.numpy()
+        pad_len, valid_len, spans, b0 = [], [], [], 0
+        for g, li in zip(groups, lens):
+            t = int(output_frames(li))
+            if t < 1:
+                raise ValueError(f"input of {li} samples is shorter than one encoder frame (400 samples)")
+            for c in g:
+                n = len(c)
+                w[b0, :n] = c
+                w[b0, n:] = 0.0
+                valid_len.append(n)
+                pad_len.append(li)
+                b0 += 1
+            spans.append((b0 - len(g), len(g), t))
+        return Pack(wav=wav.to(device, non_blocking=True), mask=None, valid_len=valid_len if self.return_attention_mask else None,
+                    pad_len=pad_len, spans=spans)
+
     @staticmethod
     def zero_mean_unit_var_norm(x: np.ndarray) -> np.ndarray:
         return ((x - x.mean()) / np.sqrt(x.var() + 1e-7)).astype(np.float32)
@@ -126,11 +164,13 @@ class SpeechT5FeatureExtractorMI355X:
         pin = bool(self.pin_memory and torch.cuda.is_available())  # written straight into pinned memory (torch caches these blocks)
         x = torch.empty((B, lmax), dtype=torch.float32, pin_memory=pin)
         m = torch.empty((B, lmax), dtype=torch.int32, pin_memory=pin)
+        xn, mn = x.numpy(), m.numpy()  # filled through numpy views: a fifth of the interpreter time of torch slice assignments
         for i, c in enumerate(clips):
-            x[i, :len(c)] = torch.from_numpy(c)
-            x[i, len(c):] = float(self.padding_value)
-            m[i, :len(c)] = 1
-            m[i, len(c):] = 0
+            n = len(c)
+            xn[i, :n] = c
+            xn[i, n:] = self.padding_value
+            mn[i, :n] = 1
+            mn[i, n:] = 0
         out = BatchFeature(input_values=x)
         if self.return_attention_mask:
             out["attention_mask"] = m

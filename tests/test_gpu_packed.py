@@ -182,15 +182,21 @@ def test_packed_c_abi_error_codes():
     status = torch.zeros(int(lib.loco_status_bytes()), dtype=torch.uint8).pin_memory()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def call(pad, b=B, status_=status, ws_bytes=None):
+    def call(pad, b=B, status_=status, ws_bytes=None, vl=None, mask=None):
         arr = (C.c_int64 * len(pad))(*pad) if pad is not None else None
-        return lib.loco_forward_packed(enc._handle, 1, C.c_void_p(x.data_ptr()), None, b, L, arr, C.c_void_p(out.data_ptr()), None, None,
+        vl_arr = (C.c_int64 * len(vl))(*vl) if vl is not None else None
+        return lib.loco_forward_packed(enc._handle, 1, C.c_void_p(x.data_ptr()), C.c_void_p(mask.data_ptr()) if mask is not None else None, vl_arr, b, L, arr,
+                                       C.c_void_p(out.data_ptr()), None, None,
                                        C.c_void_p(ws.data_ptr()), ws.numel() if ws_bytes is None else ws_bytes, st,
                                        C.c_void_p(status_.data_ptr()) if status_ is not None else None)
 
     assert call([L, L, 8000, 8000]) == 0
     torch.cuda.synchronize()
     assert lib.loco_status_check(C.c_void_p(status.data_ptr()), None, 0) in (0, -5)   # zeros in: range verdict either way, a valid block
+    assert call([L, L, 8000, 8000], vl=[L, 9000, 8000, 500]) == 0
+    torch.cuda.synchronize()
+    assert call([L, L, 8000, 8000], vl=[L, L, 8001, 8000]) == -1 and b"valid_len[2]" in lib.loco_last_error()
+    assert call([L, L, 8000, 8000], vl=[L, L, 8000, 8000], mask=torch.ones(B, L, dtype=torch.int32, device="cuda")) == -1
     assert call([L, L, L + 1, L]) == -1 and b"pad_len[2]" in lib.loco_last_error()
     assert call([L, L, 399, L]) == -1
     assert call(None) == -1

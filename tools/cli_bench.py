@@ -73,10 +73,13 @@ if ref_dir is not None:
     ref_folder = os.path.join(ref_dir, "devel", "audio")
     extract.main(["-m", "audio", "-s", "devel", "--synthetic", "256", "--synthetic-seconds", "6", "--synthetic-min-seconds", "2", "--random-init", "--pack", "32",
                   "--out", tempfile.mkdtemp(prefix="cli_warm_", dir=shm)])
-    for g, k, th, sk in ((8, 2, 12, 8), (16, 2, 12, 8), (32, 2, 12, 8), (64, 2, 12, 8), (32, 2, 16, 12), (32, 3, 16, 12)):
+    configs = [(8, 2, 12, 8, 0.5), (16, 2, 12, 8, 0.5), (32, 2, 12, 8, 0.5), (64, 2, 12, 8, 0.5), (32, 2, 8, 8, 0.5), (32, 2, 12, 8, 5)]
+    if "--packs" in sys.argv:  # G:inflight:loader threads:sink threads:gil switch ms, comma separated
+        configs = [tuple(float(v) if "." in v else int(v) for v in c.split(":")) for c in sys.argv[sys.argv.index("--packs") + 1].split(",")]
+    for g, k, th, sk, gil in configs:
         out = tempfile.mkdtemp(prefix=f"cli_bench_pack{g}_", dir=shm)
         st = extract.main(["-m", "audio", "-s", "devel", "--data-path", root, "--random-init", "--loader-threads", str(th), "--sink-threads", str(sk),
-                           "--out", out, "--pack", str(g), "--inflight", str(k)])
+                           "--out", out, "--pack", str(g), "--inflight", str(k), "--gil-switch-ms", str(gil)])
         dt = st["seconds"]
         assert st["frames"] == frames and st["utterances"] == N, st
         folder = os.path.join(out, "devel", "audio")
@@ -91,10 +94,10 @@ if ref_dir is not None:
             worst = max(worst, float(np.linalg.norm(a["embedding"] - e64) / np.linalg.norm(e64)))
         assert worst < 5e-6, worst
         shutil.rmtree(out, ignore_errors=True)
-        r = dict(pack=g, inflight=k, loader_threads=th, sink_threads=sk, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1),
+        r = dict(pack=g, inflight=k, loader_threads=th, sink_threads=sk, gil_switch_ms=gil, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1),
                  files=len(names), worst_rel_l2_vs_inflight1=worst)
         results.append(r)
-        print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
+        print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads, switch interval {gil} ms): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
               f"{len(names)} pickles, worst relative L2 against the --inflight 1 pickles {worst:.2e}", flush=True)
     shutil.rmtree(ref_dir, ignore_errors=True)
 shutil.rmtree(root, ignore_errors=True)

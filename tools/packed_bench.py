@@ -37,7 +37,7 @@ for G in (4, 8, 16, 32, 64, 128):
         order = [i for w0 in range(0, NP, win) for i in sorted(range(w0, min(NP, w0 + win)), key=lambda j: batches[j]["input_values"].shape[1])]
     packs = [enc.pack_batches([batches[i] for i in order[g0:g0 + G]]) for g0 in range(0, NP, G)]
     torch.cuda.synchronize()
-    rows = sum(p[0].shape[0] * la.synth.conv_out_length(p[0].shape[1]) for p in packs)
+    rows = sum(p.wav.shape[0] * la.synth.conv_out_length(p.wav.shape[1]) for p in packs)
     for K in (1, 2, 3):
         enc.set_inflight(K)
         for p in packs[:2 * K]:
