@@ -230,7 +230,8 @@ def main():
     m = torch.from_numpy(m_np).to(dev)
 
     dp.FORCE_COLLECTIVE = bool(args.force_collective)
-    gatherer = dp.OverlappedGather()
+    collective = world > 1 or args.force_collective
+    gatherer = dp.OverlappedGather(timed=collective)
 
     def step():
         # forward, then hand the embeddings to the one RCCL all-gather of the step; the collective runs on RCCL's
@@ -254,6 +255,8 @@ def main():
     dominant = max(warm_stats, key=lambda s_: s_["ms"])["name"] if warm_stats else None
     enc.set_profiling_filter(dominant)
     enc.profile_reset()
+    gatherer.blocked_ms()  # forget the warm-up's waits
+    gathers0, bytes0 = gatherer.gathers, gatherer.bytes_gathered
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -267,6 +270,34 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert gathered.shape[0] == world * B
+    # ---- what the first multi-GPU run needs to explain itself: per-rank step time, how long the forward's stream
+    # stood still for the collective, bytes gathered, and a check that every rank's block of the gathered tensor IS that rank's
+    multi = None
+    if collective:
+        blocked_ms = gatherer.blocked_ms()
+        mine = torch.tensor([elapsed / args.steps * 1e3, blocked_ms / args.steps], dtype=torch.float64, device=dev)
+        every = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every.view(-1), mine)
+        probe = y[0, 0].contiguous()  # 768 floats: row 0 of this rank's first clip, as this rank computed it
+        probes = torch.empty((world, probe.numel()), dtype=probe.dtype, device=dev)
+        dist.all_gather_into_tensor(probes.view(-1), probe)
+        blocks_ok = [bool(torch.equal(gathered[r * B, 0], probes[r])) for r in range(world)]
+        every = every.cpu()
+        step_ms = every[:, 0].tolist()
+        multi = {"world_size_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
+                 "per_rank_ms_per_step": {"min": round(min(step_ms), 3), "max": round(max(step_ms), 3),
+                                          "rank_of_max": int(max(range(world), key=lambda r: step_ms[r])),
+                                          "all": [round(v, 3) for v in step_ms]},
+                 "stream_blocked_by_gather_ms_per_step": {"this_rank": round(blocked_ms / args.steps, 4),
+                                                         "max": round(float(every[:, 1].max()), 4),
+                                                         "all": [round(v, 4) for v in every[:, 1].tolist()],
+                                                         "note": "hipEvents around every wait for the previous step's all-gather on the "
+                                                                 "stream that waits: 0 = the collective finished under the next forward"},
+                 "gathers_in_timed_region": gatherer.gathers - gathers0,
+                 "gathered_bytes_per_step": (gatherer.bytes_gathered - bytes0) // max(1, gatherer.gathers - gathers0),
+                 "every_ranks_block_matches_its_probe_row": blocks_ok}
+        if rank == 0:
+            assert all(blocks_ok), f"gathered blocks do not match their ranks' own rows: {blocks_ok}"
     if args.force_collective and world == 1:  # the collective really ran (RCCL, device tensors) and returned the rank's own rows
         assert gathered.data_ptr() != y.data_ptr() and torch.equal(gathered, y), "all_gather_into_tensor at world size 1 changed the embeddings"
     # the default range policy ("fp32": re-run out-of-range batches on the exact-fp32 kernels) was active; a re-run inside the
@@ -327,6 +358,8 @@ def main():
             "whole_path_tflops": round(whole, 2),
             "roofline": roofline, "kernels": kernels,
         }
+        if multi is not None:
+            result["multi_gpu"] = multi
         # the other precision modes, short runs (3 steps), for reference: the exact-fp32 mode ("alt_precision") and the opt-in
         # two-term mode ("opt_in_precision": weights rounded to fp16, ~9e-4 instead of ~1e-6 -- never what `value` reports)
         if world == 1 and not args.no_alt:

@@ -104,12 +104,18 @@ class OverlappedGather:
     batch is only needed by the consumer -- sink or classifier -- one step later).  ``submit`` waits for the previous
     gather, then starts this one; ``finish`` waits for the last.  Output buffers alternate between two slots."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, timed: bool = False):
         self.group = group
         self._work = None
         self._bufs = [None, None]
         self._i = 0
         self.result = None
+        # timed: every wait is bracketed by two events on the stream that waits -- nothing else runs between them there, so their
+        # distance is how long that stream stood still for the collective (0 when the gather had finished under the next forward)
+        self.timed = timed
+        self._waits = []
+        self.gathers = 0
+        self.bytes_gathered = 0
 
     def submit(self, local: torch.Tensor):
         world, _ = _world(self.group)
@@ -126,13 +132,32 @@ class OverlappedGather:
         self._work = dist.all_gather_into_tensor(buf, self._src, group=self.group, async_op=True)
         self._pending = buf
         self._i ^= 1
+        self.gathers += 1
+        self.bytes_gathered += buf.numel() * buf.element_size()
 
     def finish(self):
         if self._work is not None:
-            self._work.wait()
+            if self.timed and self._pending.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self._work.wait()
+                b.record()
+                self._waits.append((a, b))
+            else:
+                self._work.wait()
             self._work = None
             self.result = self._pending
         return self.result
+
+    def blocked_ms(self, reset: bool = True) -> float:
+        """Sum over the waits so far of the time the waiting stream stood still (timed=True; synchronises those events)."""
+        total = 0.0
+        for a, b in self._waits:
+            b.synchronize()
+            total += a.elapsed_time(b)
+        if reset:
+            self._waits = []
+        return total
 
 
 def gather_ragged(local: torch.Tensor, local_ids: Sequence[int], n_total: int, group=None):

@@ -696,6 +696,22 @@ class SpeechT5ForSpeechToTextMI355X(nn.Module):
         self.eval()
 
     @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, precision: str = "f16x3", **_unused):
+        """``SpeechT5ForSpeechToText.from_pretrained(...)`` of the fine-tuned script (…finetuned…py:95) for a checkpoint ON
+        DISK: a directory holding ``model.safetensors`` / ``pytorch_model.bin`` (or their sharded index), one such file, or a hub
+        name that is already in the local HuggingFace cache -- nothing is ever downloaded.  Keeps ``speecht5.encoder.prenet.*``
+        and ``speecht5.encoder.wrapped_encoder.*`` (either spelling of the weight-normed positional conv), takes the layer count
+        from the keys, and fails BY NAME on anything the encoder needs and the file lacks (load_state_dict(strict=True))."""
+        import re
+        from . import checkpoint_map
+        checkpoint_map.check_hf_config(str(pretrained_model_name_or_path))
+        pre, enc = checkpoint_map.load_hf_checkpoint(str(pretrained_model_name_or_path))
+        ids = [int(m_.group(1)) for m_ in (re.match(r"layers\.(\d+)\.", k) for k in enc) if m_]
+        if not ids:
+            raise KeyError(f"{pretrained_model_name_or_path}: no speecht5.encoder.wrapped_encoder.layers.N.* tensors")
+        return cls.from_state_dicts(pre, enc, layers=max(ids) + 1, precision=precision)
+
+    @classmethod
     def from_state_dicts(cls, prenet_state_dict, encoder_state_dict, layers: int = LAYERS, precision: str = "f16x3"):
         """What the base script does after from_pretrained (…base…py:98-100), minus the hub download."""
         model = cls(layers, precision)

@@ -134,7 +134,8 @@ def test_g5_T4096_long_clip(precision):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("lengths,mask", [([400], True), ([719], False), ([16000, 9600, 400], True), ([30000, 30000], False)])
+@pytest.mark.parametrize("lengths,mask", [([400], True), ([719], False), ([16000, 9600, 400], True), ([30000, 30000], False),
+                                          ([80000], True)])  # [1, 80000]: BASELINE.json configs[0], the single 5 s utterance, as such
 def test_against_oracle_on_the_box(lengths, mask, oracle, precision):
     out, _, (x, msk, sd) = run(lengths, mask=mask, precision=precision)
     ref = oracle.encode(x, msk if mask else None, sd)
@@ -424,3 +425,24 @@ def test_two_streams_on_a_mid_size_batch():
         assert rel_l2(two, one) < 5e-6
     finally:
         enc.streams = 2
+
+
+def test_from_pretrained_gives_the_bits_of_from_state_dicts(tmp_path):
+    """a checkpoint directory on disk (model.safetensors with the keys of SpeechT5ForSpeechToText, decoder tensors
+    beside them) through from_pretrained -- the fine-tuned script's call, …finetuned…py:95 -- against the same weights handed over
+    as the two state dicts (the base script's calls, …base…py:99-100): bit-identical output."""
+    from safetensors.torch import save_file
+    layers = 3
+    sd = la.synth.encoder_state_dict(5, layers=layers)
+    named = {"speecht5.encoder." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    named["speecht5.decoder.wrapped_decoder.layer_norm.weight"] = torch.ones(768)
+    save_file(named, str(tmp_path / "model.safetensors"))
+    a = la.SpeechT5ForSpeechToTextMI355X.from_pretrained(str(tmp_path)).cuda()
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    b = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                         {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=layers).cuda()
+    x, m = la.synth.batch([40000, 25000], first_index=9)
+    xa, ma = torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda()
+    ya = a.speecht5.encoder(input_values=xa, attention_mask=ma).last_hidden_state
+    yb = b.speecht5.encoder(input_values=xa, attention_mask=ma).last_hidden_state
+    assert a.speecht5.encoder.num_layers == layers and torch.equal(ya, yb) and bool(torch.isfinite(ya).all())

@@ -37,6 +37,14 @@ def test_bench_with_a_real_rccl_all_gather_at_world_size_one():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
     assert "forced in a process group of one rank and checked" in d["config"]["collective"]
     assert d["config"]["workload"].startswith("SpeechT5-base speech encoder, synthetic 16 kHz 10 s clips, batch 8")
+    # the diagnostics a first multi-GPU run needs: present, and sane at world size 1
+    mg = d["multi_gpu"]
+    assert mg["world_size_seen_by_rccl"] == 1 and mg["backend"] == "nccl"
+    assert mg["per_rank_ms_per_step"]["rank_of_max"] == 0 and len(mg["per_rank_ms_per_step"]["all"]) == 1
+    assert abs(mg["per_rank_ms_per_step"]["max"] - d["ms_per_step"]) < 0.05 * d["ms_per_step"] + 0.01
+    assert mg["stream_blocked_by_gather_ms_per_step"]["this_rank"] >= 0.0
+    assert mg["gathers_in_timed_region"] == 3 and mg["gathered_bytes_per_step"] == 8 * 499 * 768 * 4
+    assert mg["every_ranks_block_matches_its_probe_row"] == [True]
 
 
 def _launcher_env():
