@@ -33,7 +33,6 @@ namespace loco {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDT = BK + 4;  // padded LDS row (floats)
-constexpr int BK2 = 16, LDT2 = BK2 + 4;  // small-k-tile variant: 40 KB of LDS, 3 workgroups per CU
 constexpr int kGemmThreads = 256;
 
 struct TileCoord {
@@ -212,190 +211,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
 #undef LOCO_KTILE
 #undef LOCO_LOAD_FRAGS
 #undef LOCO_MFMA16
-
-    // epilogue.  The MFMAs were issued as D = W_tile * A_tile^T, so acc[i][j][e] is
-    //   C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]:
-    // each lane owns 4 consecutive n per register quad -> 16-byte stores (16 per sub-tile pair instead of 64
-    // dword stores; the store tail of a 128x128 tile is issue-bound, not bandwidth-bound).
-    float* __restrict__ C = p.C + coff;
-    const float* __restrict__ R = (EPI == kEpiResidual) ? p.R + coff : nullptr;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 64 + i * 32 + r;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * h;
-                if (n < p.N) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = tot[i][j][4 * g + e] + acc[i][j][4 * g + e];
-                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                    if (EPI == kEpiGelu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                    }
-                    if (EPI == kEpiResidual) v += *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
-                    *reinterpret_cast<f32x4*>(C + (long)m * p.ldc + n) = v;
-                }
-            }
-        }
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(kGemmThreads, 3) void gemm_f32_bk16_kernel(GemmArgs p, int tiles_m, int tiles_n, int nblk) {
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDT2];
-
-    const TileCoord tc = map_block(blockIdx.x, nblk, tiles_m, tiles_n);
-    const int z1 = tc.z / p.nb2, z2 = tc.z % p.nb2;
-    const float* __restrict__ A = p.A + z1 * p.sA1 + z2 * p.sA2;
-    const float* __restrict__ W = p.W;
-    const long coff = z1 * p.sC1 + z2 * p.sC2;
-    const int m0 = tc.mt * BM, n0 = tc.nt * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
-
-    // staging map: float4 index f = tid + 256*q  ->  row f/4, k4 = f%4
-    const int srow = tid >> 2, sk = (tid & 3) * 4;
-    const float* ga[2];
-    const float* gw[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        int ra = m0 + srow + 64 * q;
-        ra = ra < p.M ? ra : p.M - 1;  // clamp: rows past M are computed on valid data and never stored
-        int rw = n0 + srow + 64 * q;
-        rw = rw < p.N ? rw : p.N - 1;
-        ga[q] = A + (long)ra * p.lda + sk;
-        gw[q] = W + (long)rw * p.ldw + sk;
-    }
-
-    // BLOCKED ACCUMULATION (round 3).  One v_mfma_f32_32x32x2_f32 adds two products to its accumulator, so a dot product over K is a
-    // chain of K/2 roundings -- 384 for K = 768, 1 536 for the second feed-forward GEMM -- where a CPU GEMM's vector lanes and
-    // unrolled partial sums make it a tree.  On well-conditioned models nobody sees the difference; on the outlier-channel weight
-    // family (golden g10) this mode was 2-4x torch's fp32 error per layer and 2e-4 of HF-in-float64 by layer 7 -- the "exact"
-    // fallback less accurate than the default split mode it backs up.  Every four k-tiles the running block sum `acc` is folded into
-    // `tot` (64 vector adds per lane) and restarted: chains of 64 roundings per block and K / 128 block sums.  g10: 2.0e-4 -> 1.0e-4
-    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the 256
-    // registers of the two-workgroups-per-CU form (eight of the staging registers spill inside the loop) -- this mode's GEMM goes from
-    // 0.80 to 0.74 of the fp32 MFMA peak (104 -> 113 ms per 30 s x 32 step).  It is the accuracy fallback: accuracy wins.  (Folding
-    // every eight k-tiles instead costs the same registers and gave 1.14e-4 / 6.2e-5.)
-    f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.f; tot[i][j][e] = 0.f; }
-#define LOCO_FLUSH_ACC(every_)                                                                  \
-    if (((kt + 1) & ((every_) - 1)) == 0 && kt + 1 < nk) {                                      \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
-            _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                  \
-                tot[i_][j_] += acc[i_][j_];                                                     \
-                _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) acc[i_][j_][e_] = 0.f;        \
-            }                                                                                   \
-    }
-
-    f32x4 ra4[2], rw4[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        ra4[q] = *reinterpret_cast<const f32x4*>(ga[q]);
-        rw4[q] = *reinterpret_cast<const f32x4*>(gw[q]);
-    }
-    {
-        float* la = lds[0];
-        float* lw = lds[0] + BM * LDT2;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            *reinterpret_cast<f32x4*>(la + (srow + 64 * q) * LDT2 + sk) = ra4[q];
-            *reinterpret_cast<f32x4*>(lw + (srow + 64 * q) * LDT2 + sk) = rw4[q];
-        }
-    }
-    __syncthreads();
-
-    // fragment offsets of this lane inside a buffer (floats): A rows wm*64 + {0,32} + r, W rows BM + wn*64 + {0,32} + r
-    const int fa = (wm * 64 + r) * LDT2 + 8 * h;
-    const int fw = (BM + wn * 64 + r) * LDT2 + 8 * h;
-
-#define LOCO_LOAD_FRAGS(buf, k4, A0, A1, B0, B1)                                        \
-    A0 = *reinterpret_cast<const f32x4*>((buf) + fa + (k4) * 4);                        \
-    A1 = *reinterpret_cast<const f32x4*>((buf) + fa + 32 * LDT2 + (k4) * 4);             \
-    B0 = *reinterpret_cast<const f32x4*>((buf) + fw + (k4) * 4);                        \
-    B1 = *reinterpret_cast<const f32x4*>((buf) + fw + 32 * LDT2 + (k4) * 4);
-#define LOCO_MFMA16(A0, A1, B0, B1)                                                     \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0[e], A0[e], acc[0][0], 0, 0, 0); \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1[e], A0[e], acc[0][1], 0, 0, 0); \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0[e], A1[e], acc[1][0], 0, 0, 0); \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1[e], A1[e], acc[1][1], 0, 0, 0); \
-    }
-
-    // Software pipeline, skewed by a quarter tile: the fragments of quarter q+1 are read while the 16 MFMAs
-    // of quarter q issue, and the LAST quarter of tile kt is computed AFTER the barrier that publishes tile
-    // kt+1 -- its 1024 MFMA cycles cover the barrier skew and the LDS latency of the next tile's first
-    // fragments, so a wave never waits on LDS with an idle matrix pipe.
-    const int nk = p.K / BK2;
-    int cur = 0;
-    f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
-    f32x4 rc4[2], rd4[2];  // second staging set: global loads run TWO k-tiles ahead of the MFMAs
-    LOCO_LOAD_FRAGS(lds[0], 0, xa0, xa1, xb0, xb1)
-    if (nk > 1) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            ra4[q] = *reinterpret_cast<const f32x4*>(ga[q] + BK2);
-            rw4[q] = *reinterpret_cast<const f32x4*>(gw[q] + BK2);
-        }
-    }
-
-#define LOCO_KTILE(SA, SW, NA, NW)                                                              \
-    {                                                                                           \
-        const bool more = kt + 1 < nk;                                                          \
-        if (kt + 2 < nk) {                                                                      \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                     \
-                NA[q] = *reinterpret_cast<const f32x4*>(ga[q] + (long)(kt + 2) * BK2);           \
-                NW[q] = *reinterpret_cast<const f32x4*>(gw[q] + (long)(kt + 2) * BK2);           \
-            }                                                                                   \
-        }                                                                                       \
-        const float* lb = lds[cur];                                                             \
-        LOCO_LOAD_FRAGS(lb, 1, ya0, ya1, yb0, yb1)                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(xa0, xa1, xb0, xb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        if (more) {                                                                             \
-            float* na = lds[cur ^ 1];                                                           \
-            float* nw = lds[cur ^ 1] + BM * LDT2;                                               \
-            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                     \
-                *reinterpret_cast<f32x4*>(na + (srow + 64 * q) * LDT2 + sk) = SA[q];            \
-                *reinterpret_cast<f32x4*>(nw + (srow + 64 * q) * LDT2 + sk) = SW[q];            \
-            }                                                                                   \
-        }                                                                                       \
-        __syncthreads();                                                                        \
-        cur ^= 1;                                                                               \
-        if (more) { LOCO_LOAD_FRAGS(lds[cur], 0, xa0, xa1, xb0, xb1) }                          \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        /* no block flush in this three-workgroups-per-CU form: it has 168 registers per lane and a second accumulator set spills */ \
-    }
-
-    // Software pipeline (see header): global loads two k-tiles ahead (two register sets, loop unrolled by 2),
-    // LDS fragments a quarter tile ahead, last quarter computed after the barrier.
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        LOCO_KTILE(ra4, rw4, rc4, rd4)
-        ++kt;
-        LOCO_KTILE(rc4, rd4, ra4, rw4)
-        --kt;
-    }
-    if (kt < nk) LOCO_KTILE(ra4, rw4, rc4, rd4)
-#undef LOCO_KTILE
-#undef LOCO_LOAD_FRAGS
-#undef LOCO_MFMA16
+#undef LOCO_FLUSH_ACC
 
     // epilogue.  The MFMAs were issued as D = W_tile * A_tile^T, so acc[i][j][e] is
     //   C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]:
@@ -439,15 +255,15 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     const long nblk = (long)tiles_m * tiles_n * a.nb1 * a.nb2;
     if (nblk <= 0 || nblk > 0x7fffffffL) return hipErrorInvalidValue;
     dim3 grid((unsigned)nblk), block(kGemmThreads);
-    // Variant choice, measured on the encoder's shapes (tools/gemm_bench.py): the GELU epilogue is VALU-heavy (64 erff
-    // per lane); with three workgroups per CU (BK = 16, 40 KB LDS, 154 VGPRs) more of it hides under other
-    // waves' MFMAs (+2..3 % on FFN1 and the conv layers); everything else is equal or slightly better at BK = 32.
+    // One kernel for every epilogue.  (Until round 4 the GELU GEMMs -- FFN1 and conv layers 1-6, K up to 1 536 -- ran on a BK = 16,
+    // three-workgroups-per-CU variant that was 2-3 % faster and had no registers for the blocked accumulation above: chains of 768
+    // roundings in exactly the GEMMs with the longest K.  This mode is the accuracy fallback; the variant is gone.)
     switch (a.epilogue) {
         case kEpiNone:
             hipLaunchKernelGGL((gemm_f32_kernel<kEpiNone>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
             break;
         case kEpiGelu:
-            hipLaunchKernelGGL((gemm_f32_bk16_kernel<kEpiGelu>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
+            hipLaunchKernelGGL((gemm_f32_kernel<kEpiGelu>), grid, block, 0, s, a, tiles_m, tiles_n, (int)nblk);
             break;
         case kEpiResidual:
             if (!a.R) return hipErrorInvalidValue;

@@ -90,7 +90,9 @@ def test_g10_second_weight_family_hf_init_with_outlier_channels(precision):
     # products per MFMA in a tree and 24 such partial sums per K = 768; the exact-fp32 MFMA (32x32x2) chains two products per
     # instruction -- since round 3 in blocks of 64 roundings folded into a second accumulator (gemm_f32.hip; one chain of 384 ... 1 536
     # before: 2.0e-4 at layer 7) -- and the network amplifies a layer's error ~100x by layer 7 (tools/g10_probe.py).
-    bar = {"f16x3": 1e-4, "f32": 2e-4}[precision]
+    # round 4: the GELU GEMMs of the f32 mode (FFN1, conv 1-6: the longest K) no longer run on the variant without blocked
+    # accumulation -- 1.0e-4 -> 3.9e-5 at layer 7, 4.3e-5 -> 1.7e-5 at the last: the range fallback is not the weaker arithmetic any more
+    bar = {"f16x3": 1e-4, "f32": 5e-5}[precision]
     assert max(errs) < bar, msg
     assert errs[-1] < 2 * float(g["hf_fp32_error"][-1]), msg
     for i in range(6):

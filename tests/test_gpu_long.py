@@ -211,3 +211,32 @@ def test_the_range_fallback_runs_a_ragged_ten_minute_batch(oracle):
     rows = [0, 200, nv - 1, nv, 29998]
     ref = oracle.encoder_layer_rows(out.hidden_states[0][1].cpu(), rows, nv, sd, "wrapped_encoder.layers.0.", pe_k)
     assert rel_l2(out.hidden_states[1][1, rows], ref) < 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_g11_one_ten_minute_clip_end_to_end(precision):
+    """the ACCUMULATED error of the whole chain at configs[2]'s length.  The stage-by-stage checks above feed every
+    stage with the GPU's own input; this runs ONE 10-minute clip (T = 29 999) from waveform to last_hidden_state and compares probe
+    rows of the output and of hidden states 0, 1, 6, 11, 12, and the norms of all 13, with fixture g11 -- written by the CPU ORACLE
+    (fp32, blocked attention; HF itself needs 230 GB at this length; the oracle is pinned by HF up to T = 4 096, g5)."""
+    from conftest import golden, record_figure
+    g = golden("g11_10min_oracle.npz")
+    n = int(g["lengths"][0])
+    rows = torch.from_numpy(g["rows"])
+    m, _ = model(precision=precision)
+    enc = m.speecht5.encoder
+    x = torch.from_numpy(la.synth.clip(int(g["clip_index"]), n)[None]).cuda()
+    st = {}
+    out = enc(input_values=x, output_hidden_states=True, stage_taps=st)
+    torch.cuda.synchronize()
+    assert not enc.last_range_fallback
+    y = out.last_hidden_state
+    assert tuple(y.shape) == (1, 29_999, 768) and bool(torch.isfinite(y).all())
+    errs = {"prenet": rel_l2(st["prenet"][0, rows], g["prenet"]), "last": rel_l2(y[0, rows], g["last_hidden_state"])}
+    for k, layer in enumerate(g["layers"].tolist()):
+        errs[f"hidden_{layer}"] = rel_l2(out.hidden_states[layer][0, rows], g["hidden_states"][k])
+    norms = [abs(float(h.double().norm()) / g["hidden_stats"][i, 0] - 1) for i, h in enumerate(out.hidden_states)]
+    record_figure("g11_ten_minute_clip_end_to_end", precision=precision, rel_l2=errs, worst_norm_deviation=max(norms))
+    print(f"g11 ({precision}): {errs}; worst norm deviation {max(norms):.1e}")
+    assert max(errs.values()) < 2e-5, errs
+    assert max(norms) < 1e-5, norms
