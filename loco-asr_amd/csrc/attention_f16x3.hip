@@ -42,7 +42,9 @@ typedef __attribute__((address_space(1))) const void* ax_gptr_t;
 typedef __attribute__((address_space(3))) void* ax_lptr_t;
 
 // LOCO_ATTN_HACK (timing-only diagnostic builds, WRONG results; tools/ab/build_variant.sh): 1 = every table block multiplies pe_k block 0
-// (its fragments stay in the L1: what do the 80 KiB of pe_k planes per wave cost?), 2 = the table is not stored.
+// (its fragments stay in the L1: what do the 80 KiB of pe_k planes per wave cost?), 2 = the table is not stored, 3 = the main loop
+// issues only every other K / V DMA piece (half the L2 -> LDS bytes and DMA instructions per tile at unchanged MFMA / exp work: an
+// UPPER BOUND on what a workgroup of 8 waves x 32 queries sharing one K / V ring could gain -- round 4 pricing, profiles/r04_attention_8wave.txt).
 #ifndef LOCO_ATTN_HACK
 #define LOCO_ATTN_HACK 0
 #endif
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                     const f32x2 ax = __builtin_elementwise_fma(sx, k2, d2);                                            \
                     SC1[e0] = __builtin_amdgcn_exp2f(ax.x); SC1[e0 + 1] = __builtin_amdgcn_exp2f(ax.y);                \
                 }                                                                                                      \
-                if (n % 3 == 1) { /* K(t+2) into the slot of K(t), V(t+1) into the slot of V(t-1): both consumed */     \
+                if (n % 3 == 1 && (LOCO_ATTN_HACK != 3 || ((n / 3) & 1) == 0)) { /* K(t+2) into the slot of K(t), V(t+1) into the slot of V(t-1): both consumed */ \
                     AX_PIN();                                                                                          \
                     AX_DMA_PIECE(n / 3, tkn, tvn, tq & 1, (tq + 1) & 1)                                                \
                 }                                                                                                      \
