@@ -25,6 +25,12 @@ Extra objects on the line:
   kernels       per-bucket launches / ms / rate per step, from up to 5 further steps after the timed region (every launch
                 bracketed); with --warmup 0 the timed steps themselves are bracketed launch by launch, as before.
   alt_precision the other precision mode measured for 3 steps in the same process.
+  multi_gpu     (N > 1 or --force-collective) what a first multi-GPU run needs to explain itself: per-rank ms_per_step (min / max /
+                rank of max / all), how long the forward's stream stood still for the previous step's all-gather (hipEvents around
+                every wait), gathered bytes per step, the world size RCCL reports, and a check that every rank's block of the
+                gathered tensor equals a probe row that rank all-gathered separately.
+  packed_reference_batches  the REFERENCE'S operating point (batches of two 2-6 s utterances, corpus order, …base…py:67-68) on the packed
+                forward (loco_forward_packed, 32 batches per launch sequence): frames/s counting the frames the reference pickles.
   cpu_baseline  the CPU oracle (oracle/speecht5_oracle.py, torch fp32, all host cores) timed on a bounded
                 sample of the same workload (8 clips of 30 s: 1 warm-up + 3 timed passes, median) on rank 0 at
                 N = 1 -- reported, not targeted.
@@ -180,6 +186,8 @@ def main():
     ap.add_argument("--no-two-streams", action="store_true",
                     help="skip the short un-profiled run of the library's default schedule (two half-batches on two streams)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-packed", action="store_true",
+                    help="skip the short measurement of the reference's own operating point (batches of two 2-6 s utterances) on the packed forward")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1 only: create the RCCL process group of one rank anyway and issue the per-step all_gather_into_tensor on "
                          "the device embeddings (what every rank does at N > 1), then check the gathered tensor against the local one")
@@ -400,6 +408,38 @@ def main():
             enc.streams = default_streams
             result["two_streams"] = {"unit": "frames/s", "steps": args.steps, "library_default_streams": default_streams, **legs,
                                      "note": "un-profiled forward passes of the same batch, same process; no all-gather (N = 1)"}
+        # The reference's own operating point -- batch_size = 2 in corpus order (…base…py:67-68), SLURP-like 2-6 s utterances -- on the
+        # packed forward (loco_forward_packed: G of those batches per launch sequence, every clip keeps its own batch's padded length;
+        # tools/packed_bench.py is the long form).  Reported beside the headline, never instead of it.
+        if world == 1 and not args.no_packed and abs(args.clip_seconds - CLIP_SECONDS) < 1e-9:
+            npairs, G = 256, 32
+            lens = la.synth.mixed_lengths(2 * npairs, 6 * 16000, min_fraction=2.0 / 6.0)
+            fe = la.SpeechT5FeatureExtractorMI355X()
+            order = sorted(range(npairs), key=lambda p_: max(lens[2 * p_], lens[2 * p_ + 1]))  # which batches share a pack changes no embedding
+            packs, kept = [], 0
+            for g0 in range(0, npairs, G):
+                groups = [[la.synth.clip(20000 + 2 * p_ + j, lens[2 * p_ + j]) for j in (0, 1)] for p_ in order[g0:g0 + G]]
+                packs.append(fe.pack_clips(groups, dev, la.synth.conv_out_length))
+                kept += sum(nb * t for (_, nb, t) in packs[-1].spans)
+            enc.set_inflight(2)
+            for pk in packs[:2]:
+                enc.forward_packed_async(packed=pk)
+            enc.drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            tickets = [enc.forward_packed_async(packed=pk) for pk in packs]
+            for tk in tickets:
+                tk.result()
+            torch.cuda.synchronize()
+            epk = time.perf_counter() - t1
+            rows = sum(pk.wav.shape[0] * la.synth.conv_out_length(pk.wav.shape[1]) for pk in packs)
+            result["packed_reference_batches"] = {
+                "value": round(kept / epk, 1), "unit": "frames/s", "ms_per_pack": round(epk / len(packs) * 1e3, 3),
+                "workload": f"{npairs} reference batches of two synthetic 2-6 s utterances (mean {sum(lens) / len(lens) / 16000:.2f} s), packed {G} batches "
+                            f"per launch sequence, sorted by length, 2 packs in flight; frames = the frames the reference pickles (each batch's own "
+                            f"padded frames, {kept}); rows computed / frames kept = {rows / kept:.3f}",
+                "fp32_reruns": sum(int(tk.used_fp32) for tk in tickets)}
+            del tickets, packs
         # parity + CPU baseline on a bounded sample of the same workload (rank 0, N = 1 only)
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -7,8 +7,9 @@
  * manifest.txt: one line per tensor "<hf key> <ndim> <d0> [<d1> ...]" in the order the fp32 data appear in weights.bin
  * (keys exactly as `prenet.*` / `wrapped_encoder.*` of the reference's two state dicts, include/loco_asr.h).
  * wave.f32: B*L fp32 samples; out.f32 receives B*T*768 fp32 embeddings.  tests/test_gpu_cabi_c.py builds and runs this
- * and compares the file with what the Python wrapper returns (bit for bit: it is the same library call).  The second half shows
- * loco_forward_async: three forwards of the one handle in flight on three streams, each with its own workspace and status block.
+ * and compares the file with what the Python wrapper returns (bit for bit: it is the same library call).  The second part shows
+ * loco_forward_async: three forwards of the one handle in flight on three streams, each with its own workspace and status block;
+ * the third loco_forward_packed: the same batch twice plus its first clip as a batch of its own, one launch sequence.
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -107,6 +108,45 @@ int main(int argc, char** argv) {
         same += memcmp(hk, hout, nout * sizeof(float)) == 0;
     }
     printf("%d forwards in flight on %d streams: %d of %d bit-identical to the single forward\n", NF, NF, same, NF);
+
+    /* ---- several reference batches as ONE launch sequence (loco_forward_packed): the batch above twice, and between the two its
+     * first clip cut to half its length as a batch of its own.  Every clip carries the padded length of ITS OWN batch (pad_len) and
+     * its number of samples (valid_len, instead of a mask); rows of the two full copies must equal the single forward up to the fp32
+     * summation order of the GEMMs (include/loco_asr.h), and the short batch must not have disturbed them. */
+    const int BP = 2 * B + 1;
+    const long Ls = (L / 2) & ~7L, Ts = loco_output_frames(Ls);
+    int64_t* pad_len = (int64_t*)malloc(BP * sizeof(int64_t));
+    int64_t* valid_len = (int64_t*)malloc(BP * sizeof(int64_t));
+    float* hpack = (float*)calloc((size_t)BP * L, sizeof(float));
+    for (int b = 0; b < BP; ++b) {
+        const int src = b < B ? b : (b == B ? 0 : b - B - 1);
+        pad_len[b] = valid_len[b] = (b == B) ? Ls : L;
+        memcpy(hpack + (size_t)b * L, hwav + (size_t)src * L, (size_t)pad_len[b] * sizeof(float));
+    }
+    float *dpack, *dpout;
+    void* wsp;
+    const size_t wspb = loco_workspace_bytes(enc, BP, L);
+    CHECK_HIP(hipMalloc((void**)&dpack, (size_t)BP * L * sizeof(float)));
+    CHECK_HIP(hipMalloc((void**)&dpout, (size_t)BP * T * 768 * sizeof(float)));
+    CHECK_HIP(hipMalloc(&wsp, wspb));
+    CHECK_HIP(hipMemcpyAsync(dpack, hpack, (size_t)BP * L * sizeof(float), hipMemcpyHostToDevice, st[0]));
+    CHECK_LOCO(loco_forward_packed(enc, -1, dpack, NULL, valid_len, BP, L, pad_len, dpout, NULL, NULL, wsp, wspb, st[0], status[0]));
+    CHECK_HIP(hipStreamSynchronize(st[0]));
+    CHECK_LOCO(loco_status_check(status[0], NULL, 0));
+    float* hp = (float*)malloc((size_t)BP * T * 768 * sizeof(float));
+    CHECK_HIP(hipMemcpy(hp, dpout, (size_t)BP * T * 768 * sizeof(float), hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int copy = 0; copy < 2; ++copy) {
+        const float* got = hp + (size_t)(copy ? B + 1 : 0) * T * 768;
+        double num = 0.0, den = 0.0;
+        for (size_t i = 0; i < nout; ++i) { const double d = (double)got[i] - hout[i]; num += d * d; den += (double)hout[i] * hout[i]; }
+        const double rel = den > 0 ? num / den : 1.0;
+        if (rel > worst) worst = rel;
+    }
+    double short_norm = 0.0;
+    for (size_t i = 0; i < (size_t)Ts * 768; ++i) short_norm += (double)hp[(size_t)B * T * 768 + i] * hp[(size_t)B * T * 768 + i];
+    printf("packed forward of %d clips (batches of %d, 1, %d): worst squared relative L2 of the two full batches against the single forward %.3e; "
+           "the short batch has %ld frames, norm^2 %.4e\n", BP, B, B, worst, Ts, short_norm);
     loco_destroy(enc);
-    return same == NF ? 0 : 4;
+    return (same == NF && worst < 25e-12 && short_norm > 0.0) ? 0 : 4;
 }

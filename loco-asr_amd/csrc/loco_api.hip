@@ -10,6 +10,7 @@
 // past its reserved rows, mirrors HF's own auto-grow at modeling:331-333 and is done before any launch).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -87,7 +88,7 @@ struct ProfRec {
 // handle's own pinned block for loco_forward.  The host part is filled while the forward is enqueued; `words` is the target of the
 // device-to-host copy that follows the forward on its stream.
 constexpr uint32_t kStatusMagic = 0x53434f4cu;  // "LOCS"
-constexpr int kMaxPackClips = 1024;             // clips per loco_forward_packed
+constexpr int kMaxPackClips = 512;              // clips per loco_forward_packed
 struct StatusBlock {
     uint32_t magic;
     int32_t precision;                        // arithmetic mode of the forward this block describes
@@ -132,8 +133,10 @@ struct loco_encoder {
     SplitW posg_s;                 // positional conv weight as the GEMM's W: [16][48][128*48]
     int precision = 1;             // 0 = exact fp32 MFMA, 1 = fp16 x3 split MFMA (default), 2 = f16x2 (weights rounded to fp16; opt-in)
     std::vector<LayerW> layers;
-    float* sin_tab = nullptr;
-    int sin_rows = 0;
+    // published with release stores (table first, then its row count), read with acquire loads: a forward on another host thread
+    // that sees the new row count also sees the new, longer table (ensure_sin_rows; loco_forward_async allows concurrent callers)
+    std::atomic<float*> sin_tab{nullptr};
+    std::atomic<int> sin_rows{0};
     bool sin_user = false;
     std::mutex sin_mu;            // growth of the sinusoid table (ensure_sin_rows)
     std::vector<float*> retired;  // tables replaced while forwards may still have been reading them: freed at loco_destroy
@@ -441,13 +444,21 @@ int run_copy(loco_encoder* e, hipStream_t s, float* dst, const float* src, size_
     return LOCO_OK;
 }
 
-int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s) {
-    if (e->sin_rows >= rows) return LOCO_OK;
+// On success *tab is a table of at least `rows` rows: the snapshot this forward uses from here on, whatever other threads publish later.
+int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s, const float** tab) {
+    if (e->sin_rows.load(std::memory_order_acquire) >= rows) {
+        // the count is stored AFTER its table: a table loaded now is that one or a later, longer one
+        *tab = e->sin_tab.load(std::memory_order_acquire);
+        return LOCO_OK;
+    }
     // grow (HF does the same on demand, modeling:331-333); happens once per new maximum length.  Safe with other forwards of the handle
     // in flight: the new table is complete before it is published (this is the one place a forward may block its host thread), and
     // the old one is RETIRED, not freed -- forwards already enqueued on other streams keep reading it -- until loco_destroy.
     std::lock_guard<std::mutex> lock(e->sin_mu);
-    if (e->sin_rows >= rows) return LOCO_OK;
+    if (e->sin_rows.load(std::memory_order_relaxed) >= rows) {
+        *tab = e->sin_tab.load(std::memory_order_relaxed);
+        return LOCO_OK;
+    }
     int want = rows < 4002 ? 4002 : rows + 2;
     float* nt = nullptr;
     HIP_TRY(hipMalloc(&nt, (size_t)want * kHidden * sizeof(float)));
@@ -457,9 +468,10 @@ int ensure_sin_rows(loco_encoder* e, int rows, hipStream_t s) {
         (void)hipFree(nt);
         return fail(LOCO_E_HIP, "sinusoid table: %s", hipGetErrorString(err));
     }
-    if (e->sin_tab) e->retired.push_back(e->sin_tab);
-    e->sin_tab = nt;
-    e->sin_rows = want;
+    if (float* old = e->sin_tab.load(std::memory_order_relaxed)) e->retired.push_back(old);
+    e->sin_tab.store(nt, std::memory_order_release);
+    e->sin_rows.store(want, std::memory_order_release);
+    *tab = nt;
     e->sin_user = false;
     return LOCO_OK;
 }
@@ -474,6 +486,7 @@ struct Bufs {
     // packed forward (null otherwise): per clip, the conv-layer-0 frame count and the encoder frame count of its own reference batch
     const int32_t* t0_clip = nullptr;
     const int32_t* rows_clip = nullptr;
+    const float* sin_tab = nullptr;  // the sinusoid table this forward reads (a snapshot: ensure_sin_rows)
 };
 
 // ---- precision 0: every contraction on the exact-fp32 MFMA ------------------------------------------------------
@@ -526,7 +539,7 @@ int forward_f32(loco_encoder* e, const Plan& p, const float* wav, float* out, fl
     // ---- positional conv + sinusoid (HF :555-564)
     {
         Bracket br(e, s, K_POSCONV, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
-        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), e->sin_tab, frames_or_null, x0, B, T, s, bf.rows_clip));
+        HIP_TRY(launch_pos_conv(x1, e->pos_w, W(e, pn + "pos_conv_embed.conv.bias"), bf.sin_tab, frames_or_null, x0, B, T, s, bf.rows_clip));
     }
     if (e->tap_prenet && (rc = run_copy(e, s, e->tap_prenet, x0, (size_t)M * kHidden))) return rc;
     }  // !skip_prenet
@@ -682,7 +695,7 @@ int forward_f16x3(loco_encoder* e, Call& c, const Plan& p, const float* wav, flo
         a.epilogue = kEpiPosConv;
         a.out_scale = e->posg_s.inv_scale;
         a.terms = c.precision == 2 ? 2 : 3;
-        a.sin_table = e->sin_tab; a.frames = frames_or_null; a.T = T;
+        a.sin_table = bf.sin_tab; a.frames = frames_or_null; a.T = T;
         a.splitk_ws = c.splitk;  // one or two short clips: split-K over the taps (launch_gemm_split)
         Bracket br(e, s, K_POSCONV_SPLIT, 2.0 * M * (double)kHidden * kPosCg * kPosK, 8.0 * M * kHidden);
         HIP_TRY(launch_gemm_split(a, s));
@@ -878,7 +891,7 @@ void loco_destroy(loco_encoder* e) {
     (void)hipFree(e->absmax_dev);
     (void)hipFree(e->debug_counter);
     if (e->own) (void)hipHostFree(e->own);
-    (void)hipFree(e->sin_tab);
+    (void)hipFree(e->sin_tab.load());
     for (float* t : e->retired) (void)hipFree(t);
     (void)hipFree(e->text_embed);
     (void)hipFree(e->text_alpha);
@@ -907,9 +920,13 @@ int loco_set_weight(loco_encoder* e, const char* key, const float* data, const i
         HIP_TRY(hipMalloc(&d, (size_t)n * sizeof(float)));
         HIP_TRY(hipMemcpy(d, data, (size_t)n * sizeof(float), hipMemcpyDefault));
         HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(e->sin_tab);
-        e->sin_tab = d;
-        e->sin_rows = (int)shp[0];
+        {   // a weight load: the caller guarantees no forward is in flight (as for every loco_set_weight)
+            std::lock_guard<std::mutex> lock(e->sin_mu);
+            (void)hipFree(e->sin_tab.load(std::memory_order_relaxed));
+            e->sin_rows.store(0, std::memory_order_release);
+            e->sin_tab.store(d, std::memory_order_release);
+            e->sin_rows.store((int)shp[0], std::memory_order_release);
+        }
         e->sin_user = true;
         return LOCO_OK;
     }
@@ -1056,7 +1073,8 @@ int loco_finalize_weights(loco_encoder* e, void* stream) {
     }
     if (rc) return rc;
     if (speech) {
-        rc = ensure_sin_rows(e, 4002, s);
+        const float* unused_tab = nullptr;
+        rc = ensure_sin_rows(e, 4002, s, &unused_tab);
         if (rc) return rc;
     }
     // weight-determined activation ranges of precision mode f16x3 (static_range_check above)
@@ -1136,7 +1154,7 @@ namespace {
 // clip_tab: null, or (loco_forward_packed) the host table {conv0 frames [B], encoder frames [B]} of THIS (half-)batch's clips
 int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const int32_t* mask, int B, long L, float* out, int32_t* out_frames,
                 float* const* hidden_states, char* ws, hipStream_t s, const int32_t* clip_t0 = nullptr, const int32_t* clip_rows = nullptr,
-                const int32_t* clip_valid = nullptr) {
+                const int32_t* clip_valid = nullptr, const float* sin_tab = nullptr) {
     int32_t* frames = out_frames ? out_frames : reinterpret_cast<int32_t*>(ws + p.off_frames);
     float* bufA = reinterpret_cast<float*>(ws + p.off_a);
     float* bufB = reinterpret_cast<float*>(ws + p.off_b);
@@ -1157,6 +1175,7 @@ int forward_one(loco_encoder* e, Call& c, const Plan& p, const float* wav, const
 
     struct Bufs bufs{frames, frames_or_null, bufA, bufB, x0, x1, tmp, ctx, qkv, qp, ffn, reinterpret_cast<_Float16*>(ws + p.off_xs0),
                      reinterpret_cast<_Float16*>(ws + p.off_xs1), ws + p.off_c0scratch};
+    bufs.sin_tab = sin_tab;
     if (clip_t0) {
         // packed forward: the per-clip tables follow the stream into the workspace; without a mask every sample of a clip's own
         // reference batch counts, so its valid frames are that batch's frames (and a key mask is needed whatever the caller passed:
@@ -1196,7 +1215,8 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) || (reinterpret_cast<uintptr_t>(wav) & 3))
         return fail(LOCO_E_INVALID, "loco_forward: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    int rc = ensure_sin_rows(e, (int)p.T + 2, s);
+    const float* sin_tab = nullptr;  // this forward's snapshot of the sinusoid table
+    int rc = ensure_sin_rows(e, (int)p.T + 2, s, &sin_tab);
     if (rc) return rc;
     const int32_t *tab_t0 = nullptr, *tab_rows = nullptr, *tab_valid = nullptr;
     if (pad_len) {  // loco_forward_packed: validate, then derive the two per-clip frame counts into the caller's status block
@@ -1225,7 +1245,7 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     char* ws = reinterpret_cast<char*>(workspace) + kStatusDevBytes;
     if ((rc = range_begin(e, c, s))) return rc;
     if (!dual) {
-        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s, tab_t0, tab_rows, tab_valid);
+        rc = forward_one(e, c, p, wav, mask, B, L, out, out_frames, hidden_states, ws, s, tab_t0, tab_rows, tab_valid, sin_tab);
         if (rc) return rc;
         return range_end(c, s);
     }
@@ -1243,13 +1263,13 @@ int forward_impl(loco_encoder* e, int precision, StatusBlock* st, const float* w
     // From here on the side stream may hold work that reads the caller's buffers and the workspace: whatever fails below, the
     // caller's stream is joined to it before this function returns, so that "stream idle" still means "workspace free".
     c.dual = true;
-    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s, tab_t0, tab_rows, tab_valid);
+    rc = forward_one(e, c, p0, wav, mask, B0, L, out, out_frames, nullptr, ws, s, tab_t0, tab_rows, tab_valid, sin_tab);
     int rc1 = LOCO_OK;
     std::string first_error;
     if (rc) first_error = g_err;
     else rc1 = forward_one(e, c, p1, wav + (size_t)B0 * L, mask ? mask + (size_t)B0 * L : nullptr, B1, L, out + (size_t)B0 * p.T * kHidden,
                            out_frames ? out_frames + B0 : nullptr, nullptr, ws + p0.total, e->side, tab_t0 ? tab_t0 + B0 : nullptr,
-                           tab_rows ? tab_rows + B0 : nullptr, tab_valid ? tab_valid + B0 : nullptr);
+                           tab_rows ? tab_rows + B0 : nullptr, tab_valid ? tab_valid + B0 : nullptr, sin_tab);
     c.dual = false;
     if (!rc && rc1) first_error = g_err;
     const hipError_t j1 = hipEventRecord(e->ev_join, e->side);  // ... and the caller's stream continues after both halves

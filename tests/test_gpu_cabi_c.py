@@ -44,3 +44,4 @@ def test_c_host_reproduces_the_python_wrapper(tmp_path):
     assert rel < 2e-6, rel
     assert "workspace" in res.stdout
     assert "3 forwards in flight on 3 streams: 3 of 3 bit-identical" in res.stdout, res.stdout
+    assert "packed forward of 5 clips (batches of 2, 1, 2)" in res.stdout and "the short batch has 37 frames" in res.stdout, res.stdout
