@@ -197,22 +197,39 @@ def extract_text(args, items, classes, encode_labels, device, world, rank):
     if inflight > 1:
         enc.set_inflight(inflight)  # batches of transcripts are tiny (<= 2 x ~100 tokens): several in flight, results untouched
     tickets = deque()
+    pack = max(0, getattr(args, "pack", 0))
     with torch.no_grad(), sink_mod.EmbeddingSink(args.out, args.split, args.modality, args.format) as sink:
         def finish():
             i0, t0 = tickets.popleft()
-            emb = (t0.result() if hasattr(t0, "result") else t0).last_hidden_state
-            sink.submit([items[i][0] for i in i0], emb, encode_labels([items[i][4] for i in i0]))
+            res = t0.result() if hasattr(t0, "result") else t0
+            if pack:  # i0 = the index lists of the pack's batches, res = one output per batch
+                for idx_b, o in zip(i0, res):
+                    sink.submit([items[i][0] for i in idx_b], o.last_hidden_state, encode_labels([items[i][4] for i in idx_b]))
+            else:
+                sink.submit([items[i][0] for i in i0], res.last_hidden_state, encode_labels([items[i][4] for i in i0]))
 
-        for idx in dp.shard_batches(len(items), args.batch_size, world, rank):  # the reference's batches, dealt whole
+        def padded_ids(idx):
             seqs = tokenize(idx)
             T = max(len(q) for q in seqs)
             ids = np.full((len(seqs), T), 1, dtype=np.int64)  # padding="longest" with pad_token_id = 1
             for r, q in enumerate(seqs):
                 ids[r, :len(q)] = q
-            dev_ids = torch.from_numpy(ids).to(device)
-            tickets.append((idx, enc.forward_async(dev_ids) if inflight > 1 else enc(dev_ids)))
-            while len(tickets) >= inflight:
-                finish()
+            return torch.from_numpy(ids)
+
+        my = dp.shard_batches(len(items), args.batch_size, world, rank)  # the reference's batches, dealt whole
+        if pack:  # --pack G: G of those batches per forward, every row's keys ending where its own batch ends (text_encoder.forward_packed)
+            enc.set_inflight(max(1, inflight))
+            for g0 in range(0, len(my), pack):
+                group = my[g0:g0 + pack]
+                tickets.append((group, enc.forward_packed_async([padded_ids(idx) for idx in group])))
+                while len(tickets) >= max(1, inflight):
+                    finish()
+        else:
+            for idx in my:
+                dev_ids = padded_ids(idx).to(device)
+                tickets.append((idx, enc.forward_async(dev_ids) if inflight > 1 else enc(dev_ids)))
+                while len(tickets) >= inflight:
+                    finish()
         while tickets:
             finish()
     print("Done!")

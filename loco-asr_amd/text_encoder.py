@@ -131,7 +131,7 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         return ids.to(torch.int32).contiguous(), m
 
     # -- several batches of transcripts in flight (the reference's text loop is batch_size = 2 as well, …base…py:67-68,79-93) --------
-    def _enqueue(self, slot, ids32, m, out, frames, precision):
+    def _enqueue(self, slot, ids32, m, out, frames, precision, pack=None):  # pack: unused (a text pack is an ordinary masked forward)
         B, T = ids32.shape
         need = int(self._lib.loco_text_workspace_bytes(self._handle, B, T))
         if slot.workspace is None or slot.workspace.numel() < need:
@@ -157,6 +157,48 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         if not self._slots:
             self.set_inflight(2)
         ids32, m = self._check_ids(input_values, attention_mask)
+        return self._submit_text(ids32, m)
+
+    @torch.no_grad()
+    def forward_packed_async(self, batches=None, *, packed=None):
+        """Several of the reference's text batches (…base…py:79-93: ids padded to the batch's longest transcript with <pad> = 1,
+        NO attention mask -- the pads of a batch attend like tokens) as ONE forward: rows of all batches side by side, padded to the
+        pack's longest, and a key mask that ends every row where ITS OWN batch ends -- which is all a text batch's composition
+        means here (no GroupNorm, no positional conv: the text prenet is row-wise, positions count from 0 in every row).  A batch
+        given as a mapping with ``attention_mask`` (right padding) keeps that mask.  ``ticket.result()`` = one BaseModelOutput per
+        batch, ``last_hidden_state`` [B_i, T_i, 768] equal to the batch's own forward up to the fp32 summation order of the GEMMs."""
+        from .encoder import Pack
+        if self.training:
+            raise RuntimeError("the MI355X encoder path is inference-only; call .eval()")
+        if not batches:
+            raise ValueError("forward_packed: no batches")
+        device = self._device()
+        self._ensure_handle(device)
+        if self._weights_dirty:
+            self.drain()
+        if not self._slots:
+            self.set_inflight(2)
+        ids_l = [b["input_values"] if hasattr(b, "keys") else b for b in batches]
+        msk_l = [b.get("attention_mask") if hasattr(b, "keys") else None for b in batches]
+        B, T = sum(int(i.shape[0]) for i in ids_l), max(int(i.shape[1]) for i in ids_l)
+        ids = torch.full((B, T), 1, dtype=torch.int64)
+        mask = torch.zeros((B, T), dtype=torch.int32)
+        spans, b0 = [], 0
+        for i, mk in zip(ids_l, msk_l):
+            nb, t = int(i.shape[0]), int(i.shape[1])
+            ids[b0:b0 + nb, :t] = i.to("cpu")
+            mask[b0:b0 + nb, :t] = 1 if mk is None else mk.to("cpu", torch.int32)
+            spans.append((b0, nb, t))
+            b0 += nb
+        ids32, m = self._check_ids(ids.to(device), mask.to(device))
+        return self._submit_text(ids32, m, Pack(wav=ids32, mask=m, valid_len=None, pad_len=[], spans=spans))
+
+    def forward_packed(self, batches=None, *, packed=None):
+        return self.forward_packed_async(batches).result()
+
+    def _submit_text(self, ids32, m, pack=None):
+        from .encoder import ForwardTicket
+        device = ids32.device
         B, T = ids32.shape
         slot = self._slots[self._next_slot]
         self._next_slot = (self._next_slot + 1) % len(self._slots)
@@ -173,7 +215,7 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
                 for t_ in (ids32, m, out, frames):
                     if t_ is not None:
                         t_.record_stream(slot.stream)
-                ticket = ForwardTicket(self, slot, ids32, m, out, frames, self.precision)
+                ticket = ForwardTicket(self, slot, ids32, m, out, frames, self.precision, pack)
                 self._enqueue(slot, ids32, m, out, frames, self.precision)
                 ticket._done.record(slot.stream)
         slot.ticket = ticket

@@ -137,3 +137,47 @@ def test_text_forwards_in_flight_equal_one_at_a_time_bitwise(tmp_path):
     assert len(names) == 9 and names == sorted(os.listdir(folders[4]))
     for n in names:
         assert open(os.path.join(folders[1], n), "rb").read() == open(os.path.join(folders[4], n), "rb").read(), n
+
+
+def test_text_batches_packed_into_one_forward(tmp_path):
+    """Several of the reference's text batches (ids padded to the batch's longest, NO mask: the pads of a batch attend like tokens,
+    …base…py:79-93) as ONE forward whose key mask ends every row where its own batch ends (text_encoder.forward_packed): equal to the
+    batches' own forwards up to the fp32 summation order of the GEMMs; the CLI's --pack writes the same files."""
+    import importlib
+    import os
+    import pickle
+    sd = la.synth.encoder_state_dict(0, layers=2)
+    _, enc_sd = la.synth.split_state_dict(sd)
+    tpre = {k[len("text_prenet."):]: torch.from_numpy(np.asarray(v)) for k, v in la.synth.text_prenet_state_dict(0).items()}
+    model = la.SpeechT5ForTextToSpeechMI355X.from_state_dicts(tpre, {k: torch.from_numpy(v) for k, v in enc_sd.items()}, layers=2).cuda()
+    enc = model.speecht5.encoder
+    batches = []
+    for i, (n, lens) in enumerate(((57, [57, 31]), (20, [20, 20]), (90, [44, 90]), (9, [9, 3]), (33, [33, 30]), (64, [64, 1]))):
+        ids, mask = la.synth.token_ids(2, n, seed=40 + i, lengths=lens)
+        # the reference's way (no mask) for most batches, a right-padding mask for two of them
+        batches.append(dict(input_values=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)) if i in (2, 4) else torch.from_numpy(ids))
+    ref = []
+    for b in batches:
+        if isinstance(b, dict):
+            ref.append(enc(b["input_values"].cuda(), attention_mask=b["attention_mask"].cuda()).last_hidden_state.clone())
+        else:
+            ref.append(enc(b.cuda()).last_hidden_state.clone())
+    t = enc.forward_packed_async(batches)
+    outs = t.result()
+    assert len(outs) == len(batches) and not t.used_fp32
+    for o, r in zip(outs, ref):
+        assert tuple(o.last_hidden_state.shape) == tuple(r.shape)
+        assert rel_l2(o.last_hidden_state, r) < 5e-6
+    extract = importlib.import_module("loco-asr_amd.extract")
+    folders = {}
+    for name, extra in (("one", ["--inflight", "1"]), ("packed", ["--pack", "3"])):
+        out = str(tmp_path / name)
+        extract.main(["-m", "text", "-s", "devel", "--synthetic", "11", "--random-init", "--out", out] + extra)
+        folders[name] = os.path.join(out, "devel", "text")
+    names = sorted(os.listdir(folders["one"]))
+    assert len(names) == 11 and names == sorted(os.listdir(folders["packed"]))
+    for n in names:
+        with open(os.path.join(folders["one"], n), "rb") as f1, open(os.path.join(folders["packed"], n), "rb") as f2:
+            a, b = pickle.load(f1), pickle.load(f2)
+        assert a["id"] == b["id"] and a["embedding"].shape == b["embedding"].shape and (a["target"] == b["target"]).all()
+        assert rel_l2(b["embedding"], a["embedding"]) < 5e-6

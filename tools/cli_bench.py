@@ -100,6 +100,18 @@ if ref_dir is not None:
         print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads, switch interval {gil} ms): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
               f"{len(names)} pickles, worst relative L2 against the --inflight 1 pickles {worst:.2e}", flush=True)
     shutil.rmtree(ref_dir, ignore_errors=True)
+    if "--cold" in sys.argv:
+        # the same corpus through a FRESH process (python loco-asr_amd/extract.py ...): nothing cached -- the slots' multi-GB workspaces, the
+        # pinned staging buffers and the allocator's blocks are all first-time allocations inside the timed loop
+        import re, subprocess
+        for g in (32,):
+            out = tempfile.mkdtemp(prefix=f"cli_bench_cold{g}_", dir=shm)
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "loco-asr_amd", "extract.py"), "-m", "audio", "-s", "devel",
+                                "--data-path", root, "--random-init", "--loader-threads", "12", "--sink-threads", "8", "--out", out, "--pack", str(g)],
+                               capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("Encoded")]
+            print(f"cold process, --pack {g}: {line[-1] if line else r.stdout[-500:] + r.stderr[-500:]}", flush=True)
+            shutil.rmtree(out, ignore_errors=True)
 shutil.rmtree(root, ignore_errors=True)
 print(json.dumps({"corpus": {"utterances": N, "frames_padded": frames, "frames_valid": valid}, "runs": results}))
 if "--big" in sys.argv:

@@ -26,7 +26,7 @@ python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc10_FETCH_SIZE/*/*
 python3 tools/pmc_traffic.py gemm_f16x3_dma_kernel $(ls $O/pmc10_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc10_WRITE_SIZE/*/*counter_collection.csv) $O/gemm_f16x3_traffic_10minx4.json --exclude "<4, false, 8, 1," --workload 10minx4
 # the bench lines LAST: bench.py copies roofline.traffic from profiles/*_traffic.json, so the files of THIS call go there first
 # (the round prefix is the newest one present in profiles/)
-R=$(ls profiles | sed -n 's/^\(r[0-9][0-9]\)_bench_30sx32.json$/\1/p' | sort | tail -1)
+R=${LOCO_ROUND:-$(ls profiles | sed -n 's/^\(r[0-9][0-9]\)_bench_30sx32.json$/\1/p' | sort | tail -1)}  # LOCO_ROUND=r04 for a round without a bench file yet
 cp $O/gemm_f16x3_traffic.json profiles/${R}_gemm_f16x3_traffic.json
 cp $O/attention_f16x3_traffic.json profiles/${R}_attention_f16x3_traffic.json
 cp $O/attention_f16x3_traffic_10minx4.json profiles/${R}_10minx4_attention_f16x3_traffic.json
