@@ -5,11 +5,11 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/final
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 5 --no-cpu-baseline --no-alt --no-two-streams > $O/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 bench.py --steps 5 --no-cpu-baseline --no-alt --no-two-streams --no-packed > $O/stats.log 2>&1 || exit 1
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams > $O/pmc_$n.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams --no-packed > $O/pmc_$n.log 2>&1 || exit 1
   python3 tools/pmc_summary.py "$O/pmc_$n/*/*counter_collection.csv" > $O/pmc_${n}_summary.txt
   echo "pmc $n done"
 done
@@ -19,7 +19,7 @@ python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc_FETCH_SIZE/*/*co
 cp $(ls $O/stats/*/*kernel_stats.csv) $O/kernel_stats.csv
 # 10 min x 4: PMC traffic of the attention kernel at that shape (bench.py keys roofline.traffic by workload)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c -d $O/pmc10_$c --output-format csv -- python3 bench.py --clip-seconds 600 --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams > $O/pmc10_$c.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc10_$c --output-format csv -- python3 bench.py --clip-seconds 600 --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-alt --no-two-streams --no-packed > $O/pmc10_$c.log 2>&1 || exit 1
   echo "pmc 10min $c done"
 done
 python3 tools/pmc_traffic.py attention_f16x3_kernel $(ls $O/pmc10_FETCH_SIZE/*/*counter_collection.csv) $(ls $O/pmc10_WRITE_SIZE/*/*counter_collection.csv) $O/attention_f16x3_traffic_10minx4.json --workload 10minx4
