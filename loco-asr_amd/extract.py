@@ -240,7 +240,16 @@ def main(argv=None):
     ap.add_argument("--modality", "-m", choices=["text", "audio"], required=True)
     ap.add_argument("--split", "-s", choices=["train", "devel", "test", "train_synthetic"], required=True)
     ap.add_argument("--data-path", default="slurp")
-    ap.add_argument("--out", default=os.path.join("extracted", "speecht5_base"))
+    ap.add_argument("--out", default=None,
+                    help="output root; default extracted/speecht5_base (the base script's, …base…py:70) or, with --pretrained, "
+                         "extracted/speecht5 (the fine-tuned script's, …finetuned…py:63-64)")
+    ap.add_argument("--pretrained", default=None, metavar="DIR",
+                    help="the fine-tuned script's weights (…finetuned…py:95: SpeechT5ForSpeechToText.from_pretrained('microsoft/speecht5_asr')) "
+                         "from a checkpoint ON DISK: a directory with model.safetensors / pytorch_model.bin, such a file, or a hub name "
+                         "already in the local HuggingFace cache (never downloaded); replaces the two --*-state-dict pickles")
+    ap.add_argument("--resume", action="store_true",
+                    help="skip every reference batch whose utterances all have their output file already (whole batches only: batch "
+                         "composition is part of the function, a batch is never re-formed around a missing member)")
     ap.add_argument("--batch-size", type=int, default=2,
                     help="default 2 = the reference's batch_size (…base…py:67); batch composition changes the embeddings of padded "
                          "utterances (GroupNorm over the padded axis), so other values are not bit-comparable with the reference")
@@ -294,8 +303,10 @@ def main(argv=None):
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
     args = ap.parse_args(argv)
-    if args.modality == "text" and (args.window_seconds > 0 or args.gather):
-        raise SystemExit("-m text: --window-seconds / --gather apply to audio only")
+    if args.out is None:
+        args.out = os.path.join("extracted", "speecht5" if args.pretrained else "speecht5_base")
+    if args.modality == "text" and (args.window_seconds > 0 or args.gather or args.resume or args.pretrained):
+        raise SystemExit("-m text: --window-seconds / --gather / --resume / --pretrained apply to audio only")
 
     if args.gil_switch_ms > 0:
         sys.setswitchinterval(args.gil_switch_ms / 1000.0)
@@ -357,13 +368,16 @@ def main(argv=None):
         return extract_text(args, items, classes, encode_labels, device, world, rank)
 
     # ---- model
-    if args.random_init:
-        pre, enc_sd = la.synth.split_state_dict(la.synth.encoder_state_dict(0))
-        pre = {k: torch.from_numpy(v) for k, v in pre.items()}
-        enc_sd = {k: torch.from_numpy(v) for k, v in enc_sd.items()}
+    if args.pretrained:
+        model = la.SpeechT5ForSpeechToTextMI355X.from_pretrained(args.pretrained).to(device)
     else:
-        pre, enc_sd = load_state_dict_file(args.prenet_state_dict), load_state_dict_file(args.encoder_state_dict)
-    model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts(pre, enc_sd).to(device)
+        if args.random_init:
+            pre, enc_sd = la.synth.split_state_dict(la.synth.encoder_state_dict(0))
+            pre = {k: torch.from_numpy(v) for k, v in pre.items()}
+            enc_sd = {k: torch.from_numpy(v) for k, v in enc_sd.items()}
+        else:
+            pre, enc_sd = load_state_dict_file(args.prenet_state_dict), load_state_dict_file(args.encoder_state_dict)
+        model = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts(pre, enc_sd).to(device)
     print("Loaded model")
     model.eval()
     processor = la.SpeechT5FeatureExtractorMI355X(do_normalize=args.do_normalize, pin_memory=True,
@@ -378,6 +392,14 @@ def main(argv=None):
     else:  # the reference's batches: corpus order, whole batches dealt round-robin
         my_batches = dp.shard_batches(len(items), args.batch_size, world, rank)
         n_rounds = dp.rounds(len(items), args.batch_size, world)  # equal on all ranks: collectives line up
+    if args.resume:
+        if args.gather and collective:
+            raise SystemExit("--resume with --gather: rank 0 writes other ranks' files, so a rank cannot tell which of ITS batches are done")
+        folder = os.path.join(os.path.join(args.out, args.split), args.modality)
+        done = lambda b: all(os.path.exists(sink_mod.embedding_path(folder, items[i][0], args.format)) for i in b)  # noqa: E731
+        kept = [b for b in my_batches if not done(b)]
+        print(f"--resume: {len(my_batches) - len(kept)} of {len(my_batches)} batches already written, {len(kept)} to encode")
+        my_batches, n_rounds = kept, len(kept)
 
     pack, pack_window = max(0, args.pack), max(1, args.pack_window)
     if pack:

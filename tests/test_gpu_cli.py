@@ -165,3 +165,39 @@ def test_extract_cli_one_hour_recording_in_ten_minute_windows(tmp_path, oracle):
     pe_k = torch.from_numpy(sd["wrapped_encoder.embed_positions.pe_k.weight"])
     ref = oracle.encoder_layer_rows(res.hidden_states[11][1].cpu(), rows, 29999, sd, "wrapped_encoder.layers.11.", pe_k)
     assert rel_l2(emb[5][rows], ref) < 1e-5
+
+
+def test_extract_cli_pretrained_directory_and_resume(tmp_path):
+    """The fine-tuned script's flow (…finetuned…py:95,104-113) with its weights in a checkpoint directory on disk (--pretrained), and
+    --resume: after half the files have been removed, only the reference batches with a missing member are encoded again -- whole
+    batches, so every re-written file is byte-identical to the first run's."""
+    import importlib
+    import pickle
+    from safetensors.torch import save_file
+    la = importlib.import_module("loco-asr_amd")
+    extract = importlib.import_module("loco-asr_amd.extract")
+    sd = la.synth.encoder_state_dict(0)
+    ckpt = tmp_path / "speecht5_asr"
+    os.makedirs(ckpt)
+    save_file({"speecht5.encoder." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}, str(ckpt / "model.safetensors"))
+    common = ["-m", "audio", "-s", "devel", "--synthetic", "9", "--synthetic-seconds", "1.5"]
+    a, b = str(tmp_path / "from_dir"), str(tmp_path / "random_init")
+    extract.main(common + ["--pretrained", str(ckpt), "--out", a])
+    extract.main(common + ["--random-init", "--out", b])          # synth.encoder_state_dict(0): the same weights
+    fa, fb = os.path.join(a, "devel", "audio"), os.path.join(b, "devel", "audio")
+    names = sorted(os.listdir(fa))
+    assert len(names) == 9 and names == sorted(os.listdir(fb))
+    blobs = {n: open(os.path.join(fa, n), "rb").read() for n in names}
+    for n in names:
+        assert blobs[n] == open(os.path.join(fb, n), "rb").read(), n
+    # resume: remove members of batches (2,3) and (6,7) and the single (8): three batches are re-encoded, two are skipped
+    for n in (names[2], names[7], names[8]):
+        os.remove(os.path.join(fa, n))
+    mt = {n: os.path.getmtime(os.path.join(fa, n)) for n in (names[0], names[1], names[4], names[5])}
+    st = extract.main(common + ["--pretrained", str(ckpt), "--out", a, "--resume"])
+    assert st["utterances"] == 5
+    assert sorted(os.listdir(fa)) == names
+    for n in names:
+        assert open(os.path.join(fa, n), "rb").read() == blobs[n], n
+    for n, t in mt.items():
+        assert os.path.getmtime(os.path.join(fa, n)) == t, n      # untouched
