@@ -230,6 +230,22 @@ int64_t loco_resample_length(int64_t n_in, int32_t up, int32_t down);
 int loco_op_resample(const float* x, int32_t B, int64_t n_in, int64_t x_stride, const float* taps_dev, int32_t up, int32_t down,
                      int32_t taps_per_phase, float* y, int64_t n_out, int64_t y_stride, void* stream);
 
+/* ---- FLAC decoding (row a2: the corpus side of librosa.load) --------------------------------------------------------------------
+ * SLURP's recordings are FLAC files; the reference reads them through librosa.load(path, sr=16000)
+ * (/root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:56 -> soundfile -> libsndfile -> libFLAC), none of which is
+ * needed here: loco_flac_decode is a host-side decoder of the format (RFC 9639: STREAMINFO, frame CRC-8 / CRC-16, CONSTANT / VERBATIM /
+ * FIXED / LPC subframes, partitioned Rice residuals with escape, wasted bits, left-side / side-right / mid-side stereo, 4-32 bits per
+ * sample), bit-exact by construction -- with verify_md5 != 0 the MD5 signature every encoder stores in STREAMINFO is checked against the
+ * decoded samples, so each real file is its own known-answer test.  All pointers are HOST memory.
+ *   loco_flac_info    sample rate, channels, bits per sample, total samples per channel (0 = unknown: decode with enough capacity)
+ *   loco_flac_decode  mono  float32 [n] = mean over channels of sample / 2^(bits-1) (what soundfile.read(dtype="float32").mean(axis=1)
+ *                     gives the reference), and / or pcm int32 [n, channels] interleaved; either may be NULL; capacity in samples per
+ *                     channel; *n_samples = samples decoded.  LOCO_E_INVALID (message: loco_flac_last_error) for a malformed stream, a
+ *                     CRC or MD5 mismatch; LOCO_E_WORKSPACE when capacity is too small. */
+const char* loco_flac_last_error(void);
+int loco_flac_info(const void* data, size_t nbytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample, int64_t* total_samples);
+int loco_flac_decode(const void* data, size_t nbytes, float* mono, int32_t* pcm, int64_t capacity, int64_t* n_samples, int32_t verify_md5);
+
 /* ---- waveform normaliser ("next" row f-4): SpeechT5FeatureExtractor(do_normalize=True) on the device -------------------
  * HF feature_extraction_speecht5.py:119-138 (the reference's collate_fn reaches it through processor(audio=...),
  * /root/reference/speech_text/extract_speecht5_base_embeddings_slurp.py:60): per clip, over its UNPADDED samples

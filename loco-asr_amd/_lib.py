@@ -55,6 +55,9 @@ SIGNATURES = {
                                       _vp]),
     "loco_status_check": (C.c_int, [_vp, C.c_char_p, _sz]),
     "loco_status_range": (C.c_int, [_vp, _i32, C.POINTER(_f), C.POINTER(_i32), C.c_char_p, _sz]),
+    "loco_flac_last_error": (C.c_char_p, []),
+    "loco_flac_info": (C.c_int, [_vp, _sz, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "loco_flac_decode": (C.c_int, [_vp, _sz, _vp, _vp, _i64, C.POINTER(_i64), _i32]),
     "loco_resample_design": (C.c_int, [_i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), _vp]),
     "loco_resample_length": (_i64, [_i64, _i32, _i32]),
     "loco_op_resample": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),

@@ -99,6 +99,29 @@ def read_pcm_wav(path: str):
     return int(rate), x
 
 
+def read_flac(path: str):
+    """(rate, float32 mono samples) of a FLAC file through the library's host-side decoder -- bit-exact integer decoding with the
+    frame CRCs and the STREAMINFO MD5 signature verified, scaled and mixed down as soundfile.read(dtype='float32').mean(axis=1) would."""
+    import ctypes as C
+    lib = importlib.import_module("loco-asr_amd._lib").load()
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    sr, ch, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    if lib.loco_flac_info(raw, len(raw), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total)):
+        raise RuntimeError(f"{path}: {lib.loco_flac_last_error().decode()}")
+    cap = int(total.value) if total.value > 0 else 8 * len(raw)  # unknown length: FLAC rarely beats 8 samples per byte... retried below
+    while True:
+        x = np.empty(cap, dtype=np.float32)
+        n = C.c_int64()
+        rc = lib.loco_flac_decode(raw, len(raw), x.ctypes.data_as(C.c_void_p), None, cap, C.byref(n), 1)
+        if rc == -3 and total.value <= 0:
+            cap *= 4
+            continue
+        if rc:
+            raise RuntimeError(f"{path}: {lib.loco_flac_last_error().decode()}")
+        return int(sr.value), x[:n.value]
+
+
 def load_audio_16k(path: str, device=None):
     """mono float32 at 16 kHz (the reference uses librosa.load(path, sr=16000), …base…py:56): files at another rate (Fisher:
     8 kHz, podcasts: 44.1 kHz) are converted ON THE DEVICE by loco_op_resample (resample.py) and come back as CUDA tensors,
@@ -112,6 +135,8 @@ def load_audio_16k(path: str, device=None):
         except ImportError:
             _soundfile = False
     got = read_pcm_wav(path) if path.lower().endswith(".wav") else None
+    if got is None and path.lower().endswith(".flac") and not _soundfile:
+        got = read_flac(path)  # SLURP's own format, decoded by the library (include/loco_asr.h, loco_flac_decode): no libsndfile needed
     if got is not None:
         sr, x = got
     elif _soundfile:

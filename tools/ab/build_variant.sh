@@ -8,7 +8,7 @@ src=$here/../../loco-asr_amd/csrc
 out=$here/_build_$name
 mkdir -p $out
 flags="$(sed -n 's/^CXXFLAGS ?= //p' $src/Makefile | sed 's/$(ARCH)/gfx950/') $(sed -n 's/^override CXXFLAGS += //p' $src/Makefile)"
-for f in gemm_f32 gemm_f16x3 attention_f32 attention_f16x3 conv0_gn_gelu pos_conv norm_misc intent_head resample loco_api; do
+for f in gemm_f32 gemm_f16x3 attention_f32 attention_f16x3 conv0_gn_gelu pos_conv norm_misc intent_head resample flac_decode loco_api; do
   hipcc $flags "$@" -c $src/$f.hip -o $out/$f.o &
 done
 wait
