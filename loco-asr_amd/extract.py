@@ -18,8 +18,10 @@ fabric unless --gather is given.  ``--batch-size N`` / ``--bucket-by-length`` tr
 
 What differs by necessity: weights come from ``--prenet-state-dict`` / ``--encoder-state-dict`` /
 ``--text-prenet-state-dict`` (the pickled dicts the base script loads from extracted/speecht5/mapping/, …base…py:40-49)
-or ``--random-init`` -- there is no network for ``from_pretrained``; audio decoding uses soundfile or scipy (librosa is
-not installed) and the device polyphase resampler to 16 kHz; ``-m text`` (…base…py:79-93) needs the tokenizer files in a
+or ``--random-init``, or from a checkpoint directory on disk (``--pretrained DIR``: the fine-tuned script's ``from_pretrained``
+without the hub download); audio decoding needs no libsndfile -- 16 / 32-bit PCM and float WAV files and FLAC files (SLURP's format)
+are decoded here (read_pcm_wav; the library's loco_flac_decode, CRC- and MD5-verified), anything else through soundfile when it is
+installed -- followed by the device polyphase resampler to 16 kHz; ``-m text`` (…base…py:79-93) needs the tokenizer files in a
 local directory.  Targets are one-hot over the reference's fixed 101 intent labels (``ALL_CLASSES``, …base…py:32-36),
 shipped as loco-asr_amd/data/slurp_intent_classes.txt, for every split alike.
 """
