@@ -15,11 +15,13 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 NP = int(args[0]) if args else 512
 SORTED = "--sorted" in sys.argv
 REPS = int(sys.argv[sys.argv.index("--reps") + 1]) if "--reps" in sys.argv else 3
+STREAMS = int(sys.argv[sys.argv.index("--streams") + 1]) if "--streams" in sys.argv else 2  # the library's two half-batch schedule inside one forward
 sd = la.synth.encoder_state_dict(0)
 pre, enc_sd = la.synth.split_state_dict(sd)
 m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
                                                      {k: torch.from_numpy(v) for k, v in enc_sd.items()}).cuda()
 enc = m.speecht5.encoder
+enc.streams = STREAMS
 lens = la.synth.mixed_lengths(2 * NP, 6 * 16000, min_fraction=2.0 / 6.0)
 fe = la.SpeechT5FeatureExtractorMI355X()
 batches, frames = [], 0
@@ -27,7 +29,7 @@ for p in range(NP):
     b = fe(audio=[la.synth.clip(2 * p + j, lens[2 * p + j]) for j in (0, 1)], sampling_rate=16000, return_tensors="pt")
     batches.append(dict(input_values=b["input_values"], attention_mask=b["attention_mask"]))
     frames += 2 * la.synth.conv_out_length(b["input_values"].shape[1])
-print(f"{NP} reference pairs, {frames} padded frames, mean clip {sum(lens) / len(lens) / 16000:.2f} s, sorted inside windows: {SORTED}", flush=True)
+print(f"{NP} reference pairs, {frames} padded frames, mean clip {sum(lens) / len(lens) / 16000:.2f} s, sorted inside windows: {SORTED}, streams inside a forward: {STREAMS}", flush=True)
 for G in (4, 8, 16, 32, 64, 128):
     if G > NP:
         break
