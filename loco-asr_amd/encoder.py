@@ -420,6 +420,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         with torch.cuda.device(device):
             self._slots = [_Slot(device, n) for _ in range(k)]
         self._next_slot = 0
+        self._workspace_floor = 0  # a reservation belongs to the slots it was made for
 
     def drain(self):
         """Resolve every forward still in flight (their tickets stay valid)."""
