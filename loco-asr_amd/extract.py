@@ -318,7 +318,7 @@ def main(argv=None):
                          "untouched -- corpus-order pairs, every clip keeps the padded length of its own batch for GroupNorm, the "
                          "positional conv, positions and the key mask -- so the embeddings equal those of --inflight to the fp32 "
                          "summation order of the GEMMs (<= 5e-6 relative L2), not bit for bit.  0 (default) = off.  32 is a good value "
-                         "for 2-6 s utterances; --inflight then counts packs (default 2)")
+                         "for 2-6 s utterances; --inflight then counts packs (default 3, each on one stream)")
     ap.add_argument("--pack-window", type=int, default=8,
                     help="with --pack: batches are sorted by padded length inside windows of this many packs before they are packed "
                          "(which batches share a pack does not change any embedding; short batches just do not idle in long packs)")
@@ -534,7 +534,7 @@ def main(argv=None):
         torch.cuda.set_device(_device)
 
     from concurrent.futures import ThreadPoolExecutor
-    inflight = args.inflight if args.inflight > 0 else (1 if args.window_seconds >= 60 else (2 if pack else 4))
+    inflight = args.inflight if args.inflight > 0 else (1 if args.window_seconds >= 60 else (3 if pack else 4))
     # the window cache of one decoded recording is not thread-safe: windows are prepared by ONE thread, in order
     n_loaders = 0 if args.loader_threads <= 0 else (1 if args.window_seconds > 0 else args.loader_threads)
     pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 0 else None
@@ -543,6 +543,11 @@ def main(argv=None):
     encoder = model.speecht5.encoder
     if inflight > 1 or pack:
         encoder.set_inflight(max(1, inflight))
+    if pack and inflight > 1:
+        # packs in flight fill each other's tails: the two half-batch schedule INSIDE a forward (loco_set_streams) then only adds
+        # launches -- measured at 32 pairs per pack: 820 k frames/s with two streams per pack and two packs in flight, 924 k with one
+        # stream per pack, 944 k with three packs in flight (profiles/r04_packed_bench_streams.txt)
+        encoder.streams = 1
     gathers = 0
     gatherer = dp.RaggedGatherPipeline(cap=args.batch_size * max(1, pack)) if args.gather and collective else None
 
