@@ -73,7 +73,7 @@ if ref_dir is not None:
     ref_folder = os.path.join(ref_dir, "devel", "audio")
     extract.main(["-m", "audio", "-s", "devel", "--synthetic", "256", "--synthetic-seconds", "6", "--synthetic-min-seconds", "2", "--random-init", "--pack", "32",
                   "--out", tempfile.mkdtemp(prefix="cli_warm_", dir=shm)])
-    configs = [(8, 2, 12, 8, 0.5), (16, 2, 12, 8, 0.5), (32, 2, 12, 8, 0.5), (64, 2, 12, 8, 0.5), (32, 2, 8, 8, 0.5), (32, 2, 12, 8, 5)]
+    configs = [(8, 3, 12, 8, 0.5), (16, 3, 12, 8, 0.5), (32, 3, 12, 8, 0.5), (64, 3, 12, 8, 0.5), (32, 2, 12, 8, 0.5), (32, 3, 12, 8, 5)]
     if "--packs" in sys.argv:  # G:inflight:loader threads:sink threads:gil switch ms, comma separated
         configs = [tuple(float(v) if "." in v else int(v) for v in c.split(":")) for c in sys.argv[sys.argv.index("--packs") + 1].split(",")]
     for g, k, th, sk, gil in configs:
