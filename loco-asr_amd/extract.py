@@ -678,7 +678,10 @@ def main(argv=None):
     print(f"Encoded {n_mine} utterances ({frames_done} frames, padded frames included) in {t_loop:.3f} s: "
           f"{n_mine / max(t_loop, 1e-9):.1f} utterances/s, {frames_done / max(t_loop, 1e-9):,.0f} frames/s "
           f"(--inflight {inflight}{f', --pack {pack}' if pack else ''})")
-    stats = {"utterances": n_mine, "frames": frames_done, "seconds": t_loop, "inflight": inflight, "pack": pack}
+    stats = {"utterances": n_mine, "frames": frames_done, "seconds": t_loop, "inflight": inflight, "pack": pack,
+             "gpu_gib_allocated_peak": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+             "gpu_gib_reserved_peak": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)}
+    print(f"GPU memory: {stats['gpu_gib_allocated_peak']} GiB allocated at peak, {stats['gpu_gib_reserved_peak']} GiB reserved by the allocator")
     if args.gather and collective:
         import torch.distributed as dist
         print(f"Embedding gathers issued: {gathers} rounds, {gatherer.collectives} collectives (backend {dist.get_backend()}, world size {world})")
