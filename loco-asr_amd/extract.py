@@ -319,11 +319,11 @@ def main(argv=None):
                          "positional conv, positions and the key mask -- so the embeddings equal those of --inflight to the fp32 "
                          "summation order of the GEMMs (<= 5e-6 relative L2), not bit for bit.  0 (default) = off.  32 is a good value "
                          "for 2-6 s utterances; --inflight then counts packs (default 3, each on one stream)")
-    ap.add_argument("--pack-window", type=int, default=0,
+    ap.add_argument("--pack-window", type=int, default=8,
                     help="with --pack: batches are sorted by padded length inside windows of this many packs before they are packed "
                          "(which batches share a pack does not change any embedding; short batches just do not idle in long packs).  "
-                         "0 (default) = an eighth of this rank's packs, at least 8 and at most 32: rows computed per frame kept 1.05 at "
-                         "8, ~1.02 at 32; the first windows ramp 1, 2, 4, ... so a large window does not delay the first pack")
+                         "8: rows computed per frame kept 1.05; larger windows pad less (~1.02 at 32) but were measured SLOWER end to "
+                         "end (19 packs per window on 10 000 files: 814 k -> 750 k frames/s -- the host stages a whole window's packs at once)")
     ap.add_argument("--gil-switch-ms", type=float, default=0.5,
                     help="sys.setswitchinterval for the run, in ms (CPython's default is 5): the thread that enqueues forwards gives the "
                          "interpreter lock up at every library call and, with a dozen loader / writer threads runnable, waits a switch "
@@ -431,7 +431,7 @@ def main(argv=None):
         my_batches, n_rounds = kept, len(kept)
 
     pack = max(0, args.pack)
-    pack_window = args.pack_window if args.pack_window > 0 else min(32, max(8, ((n_rounds + max(1, pack) - 1) // max(1, pack)) // 8))
+    pack_window = max(1, args.pack_window)
     if pack:
         processor.pin_memory = False  # batches are copied into the pack's pinned buffer: their own staging need not be pinned
     if pack and args.bucket_by_length:
