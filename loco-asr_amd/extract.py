@@ -499,6 +499,7 @@ def main(argv=None):
             bounds.append((p0, min(n_packs, p0 + size)))
             p0 += size
             size = min(pack_window, 2 * size)
+        from collections import deque
         futs, submitted = {}, 0
         for w, (p0, p1) in enumerate(bounds):
             ahead_to = bounds[min(len(bounds) - 1, w + 2)][1] * pack  # decoding runs two windows ahead
@@ -510,15 +511,20 @@ def main(argv=None):
             order = sorted(range(lo, hi), key=lambda i: (batch_len(feats[i]), i))
             if order:  # the window's largest pack sizes the slots' workspaces at their next (re)allocation
                 encoder.reserve_workspace(sum(batch_clips(feats[i]) for i in order[-pack:]), batch_len(feats[order[-1]]) + 8)
-            jobs = []
-            for g0 in range(0, len(order), pack):
-                sel = order[g0:g0 + pack]
-                meta, fs = [my_batches[i] for i in sel], [feats[i] for i in sel]
-                jobs.append((meta, pack_pool.submit(make_pack, fs) if pack_pool else fs))
-            feats = None
-            for meta, job in jobs:
+            groups = [order[g0:g0 + pack] for g0 in range(0, len(order), pack)]
+            jobs, nxt = deque(), 0
+            for k in range(len(groups)):
+                # at most a handful of packs are being laid out at a time: each is two pinned buffers of tens of MB, and a whole
+                # window's worth at once sends the pinned allocator to the driver (hipHostMalloc stalls every other HIP call)
+                while nxt < len(groups) and len(jobs) < 5:
+                    sel = groups[nxt]
+                    meta, fs = [my_batches[i] for i in sel], [feats[i] for i in sel]
+                    jobs.append((meta, pack_pool.submit(make_pack, fs) if pack_pool else fs))
+                    nxt += 1
+                meta, job = jobs.popleft()
                 yield meta, (job.result() if pack_pool else make_pack(job))
-            for _ in range((p1 - p0) - len(jobs)):
+            feats = None
+            for _ in range((p1 - p0) - len(groups)):
                 yield [], None  # this rank has run out of batches: empty contributions keep the collectives lined up
 
     def staged_batches():
