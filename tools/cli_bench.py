@@ -76,10 +76,12 @@ if ref_dir is not None:
     configs = [(8, 3, 12, 8, 0.5), (16, 3, 12, 8, 0.5), (32, 3, 12, 8, 0.5), (64, 3, 12, 8, 0.5), (32, 2, 12, 8, 0.5), (32, 3, 12, 8, 5)]
     if "--packs" in sys.argv:  # G:inflight:loader threads:sink threads:gil switch ms, comma separated
         configs = [tuple(float(v) if "." in v else int(v) for v in c.split(":")) for c in sys.argv[sys.argv.index("--packs") + 1].split(",")]
-    for g, k, th, sk, gil in configs:
+    for cfg in configs:
+        g, k, th, sk, gil = cfg[:5]
+        win = int(cfg[5]) if len(cfg) > 5 else 8  # optional sixth field: --pack-window
         out = tempfile.mkdtemp(prefix=f"cli_bench_pack{g}_", dir=shm)
         st = extract.main(["-m", "audio", "-s", "devel", "--data-path", root, "--random-init", "--loader-threads", str(th), "--sink-threads", str(sk),
-                           "--out", out, "--pack", str(g), "--inflight", str(k), "--gil-switch-ms", str(gil)])
+                           "--out", out, "--pack", str(g), "--inflight", str(k), "--gil-switch-ms", str(gil), "--pack-window", str(win)])
         dt = st["seconds"]
         assert st["frames"] == frames and st["utterances"] == N, st
         folder = os.path.join(out, "devel", "audio")
@@ -94,10 +96,10 @@ if ref_dir is not None:
             worst = max(worst, float(np.linalg.norm(a["embedding"] - e64) / np.linalg.norm(e64)))
         assert worst < 5e-6, worst
         shutil.rmtree(out, ignore_errors=True)
-        r = dict(pack=g, inflight=k, loader_threads=th, sink_threads=sk, gil_switch_ms=gil, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1),
+        r = dict(pack=g, inflight=k, loader_threads=th, sink_threads=sk, gil_switch_ms=gil, pack_window=win, seconds=round(dt, 3), utterances_per_s=round(N / dt, 1), frames_per_s=round(frames / dt, 1),
                  files=len(names), worst_rel_l2_vs_inflight1=worst)
         results.append(r)
-        print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads, switch interval {gil} ms): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
+        print(f"--pack {g} --inflight {k} ({th} loader / {sk} sink threads, switch interval {gil} ms, window {win}): {N} utterances in {dt:.2f} s = {N / dt:.1f} utterances/s, {frames / dt:,.0f} frames/s; "
               f"{len(names)} pickles, worst relative L2 against the --inflight 1 pickles {worst:.2e}", flush=True)
     shutil.rmtree(ref_dir, ignore_errors=True)
     if "--cold" in sys.argv:
