@@ -322,8 +322,8 @@ def main(argv=None):
     ap.add_argument("--pack-window", type=int, default=8,
                     help="with --pack: batches are sorted by padded length inside windows of this many packs before they are packed "
                          "(which batches share a pack does not change any embedding; short batches just do not idle in long packs).  "
-                         "8: rows computed per frame kept 1.05; larger windows pad less (~1.02 at 32) but were measured SLOWER end to "
-                         "end (19 packs per window on 10 000 files: 814 k -> 750 k frames/s -- the host stages a whole window's packs at once)")
+                         "8: rows computed per frame kept 1.05; larger windows pad less (~1.02 at 32) for the price of more decoded audio "
+                         "held on the host -- on 10 000 files 8 / 16 / 32 measured 784-818 k / 813 k / 827 k frames/s: within the run-to-run spread")
     ap.add_argument("--gil-switch-ms", type=float, default=0.5,
                     help="sys.setswitchinterval for the run, in ms (CPython's default is 5): the thread that enqueues forwards gives the "
                          "interpreter lock up at every library call and, with a dozen loader / writer threads runnable, waits a switch "
