@@ -337,3 +337,32 @@ def test_train_head_batch_dealing_partitions_every_epoch_and_the_validation_set(
     val = [i for rank in range(W) for b in th.strided_batches(n, bs, W, rank) for i in b]
     assert sorted(val) == list(range(n))
     assert th.strided_batches(n, bs, 1, 0) == [list(range(a, min(n, a + bs))) for a in range(0, n, bs)]
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_pack_clips_is_the_processor_batch_by_batch(normalize):
+    """feature_extractor.pack_clips (extract.py --pack: every decoded clip written once into the pack's [B, L] buffer) must hold, for
+    every reference batch, exactly what SpeechT5FeatureExtractor's __call__ gives for that batch alone (…base…py:60: padding="longest",
+    zeros, optional zero-mean / unit-variance over the unpadded samples) -- the pack only adds the bookkeeping: per clip the padded
+    length of ITS batch, its own sample count (what HF reduces the attention mask to), per batch the span of rows and output frames."""
+    la = importlib.import_module("loco-asr_amd")
+    fe = la.SpeechT5FeatureExtractorMI355X(do_normalize=normalize)
+    rng = np.random.default_rng(3)
+    lens = [[40000, 23000], [400, 31999], [16000], [9000, 9000, 12000], [52001, 800]]
+    batches = [[(la.synth.clip(10 * i + j, n) * np.float32(0.5 + j) + np.float32(0.1 * i)).astype(np.float32) for j, n in enumerate(b)] for i, b in enumerate(lens)]
+    pack = fe.pack_clips(batches, "cpu", la.synth.conv_out_length)
+    assert pack.mask is None and pack.wav.dtype == torch.float32 and pack.wav.shape[1] % 8 == 0
+    assert pack.wav.shape == (sum(len(b) for b in lens), (max(max(b) for b in lens) + 7) // 8 * 8)
+    b0 = 0
+    for b, clips, span in zip(lens, batches, pack.spans):
+        ref = fe(audio=clips, sampling_rate=16000, return_tensors="pt", padding="longest")
+        nb, li = ref["input_values"].shape
+        assert span == (b0, nb, la.synth.conv_out_length(li)) and li == max(b)
+        assert torch.equal(pack.wav[b0:b0 + nb, :li], ref["input_values"])
+        assert pack.pad_len[b0:b0 + nb] == [li] * nb
+        assert pack.valid_len[b0:b0 + nb] == ref["attention_mask"].sum(1).tolist() == list(b)
+        b0 += nb
+    with pytest.raises(ValueError, match="shorter than one encoder frame"):
+        fe.pack_clips([[np.zeros(399, np.float32)]], "cpu", la.synth.conv_out_length)
+    with pytest.raises(ValueError, match="empty batch"):
+        fe.pack_clips([[]], "cpu", la.synth.conv_out_length)
