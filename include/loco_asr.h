@@ -405,7 +405,9 @@ int loco_op_attention_f16x3(const void* qhi, const void* qlo, const void* khi, c
                             void* stream);
 /* The form loco_forward runs: the relative-position table qp[b, head, i, 0..319] = q_scaled[i] . pe_k^T * pe_scale is computed by the
  * attention kernel itself (each wave for its own 32 queries) from pe_k as fp16 hi/lo planes [320][64] -- no table GEMM in front
- * of it -- into qp_scratch ([B,12,T,320] fp32: written and read back by the launch; holds the table afterwards). */
+ * of it -- into qp_scratch ([B,12,T,320] fp32: written and read back by the launch).  Only the 32-column blocks some key can read
+ * are formed: afterwards row i of qp_scratch holds columns 32 * floor((lo + 160) / 32) ... 32 * floor((hi + 160) / 32) + 31 with
+ * lo = max(i0 - (64 * ceil(frames / 64) - 1), -160), hi = min(i0 + 31, 159), i0 = 32 * floor(i / 32); its other entries are untouched. */
 int loco_op_attention_f16x3_pe(const void* qhi, const void* qlo, const void* khi, const void* klo, const void* vhi, const void* vlo,
                                const void* pe_hi, const void* pe_lo, float pe_scale, float* qp_scratch, const int32_t* frames,
                                float* ctx, int32_t B, int32_t T, void* stream);

@@ -349,6 +349,22 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         // 21 000 of a workgroup's 173 000 cycles (tools/attn_stamps.py with the timing-only build LOCO_ATTN_HACK=1).  Two rounds of
         // five blocks; a round's accumulators stay in registers until the NEXT round's DMAs have been issued, so that each wait
         // sees table stores and DMAs together (vmcnt counts both; they may complete out of order, hence vmcnt(0)).
+        //
+        // Only the blocks some key can read are formed (round 4).  The band tiles of this wave read column clip(i - j) + 160 for its 32
+        // queries i and the keys j below the end of the last key tile: a range of at most ntiles * 64 + 31 columns around the diagonal.
+        // At T = 1 499 that is the whole table for all but the first and last query blocks; at the 150 ... 300 frames of an utterance
+        // (the packed forward's regime, where this prologue was 59 % of the workgroup's cycles: every workgroup forms, stores and
+        // reads back its 160 KB at the same time) it is 5 - 8 of the 10 blocks.  The skipped blocks' MFMAs and stores are gone; the
+        // pe_k planes still pass through LDS for the whole workgroup (other waves need other blocks).  c_future / c_past (columns 0 /
+        // 319) are needed exactly when a key tile is clipped on that side, and then the range above reaches that end of the table.
+        int bmin, bmax;
+        {
+            int lo = iw0 - (ntiles * AX_BK - 1), hi = iw0 + 31;
+            lo = lo < -kRelMax ? -kRelMax : lo;
+            hi = hi > kRelMax - 1 ? kRelMax - 1 : hi;
+            bmin = (lo + kRelMax) >> 5;
+            bmax = (hi + kRelMax) >> 5;
+        }
         float cf = 0.f, cp = 0.f;
         unsigned pev[2];
 #pragma unroll
@@ -390,6 +406,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 const int plane = bb == 4 ? kBsPlane : AX_PL;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[bb][e] = 0.f;
+                const int blk_ = kBlocksPerRound * rd + bb;
+                if (blk_ < bmin || blk_ > bmax) continue;  // wave-uniform: no key of this wave's band reads these 32 columns
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const h8 fh = *reinterpret_cast<const h8*>(pb + (bb & 1) * 32 * kHeadDim + fo[ks]);
@@ -414,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 for (int e = 0; e < 16; ++e) acc[bb][e] *= pe_scale;
                 if (blk == 0) cf = acc[bb][0];                    // table column 0: lane half 0
                 if (blk == kRelN / 32 - 1) cp = acc[bb][15];      // table column 319 = 288 + 3 + 24 + 4: lane half 1
-                if (iq < T && (LOCO_ATTN_HACK != 2 || T < 0)) {
+                if (iq < T && blk >= bmin && blk <= bmax && (LOCO_ATTN_HACK != 2 || T < 0)) {
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4)
                         *reinterpret_cast<float4*>(qprow + 32 * blk + 8 * g4 + 4 * h) =

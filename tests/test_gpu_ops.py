@@ -322,7 +322,20 @@ def test_attention_f16x3_computes_the_relative_position_table_itself(B, T, frame
     # the operands the kernel really multiplies: q and pe_k as their hi + lo planes
     qd = (qh.double() + ql.double()).view(B, T, 12, 64).transpose(1, 2).cpu()
     ped = ((ph.double() + pl_.double()) / 512.0).cpu()
-    assert rel_l2(scratch, qd @ ped.t()) < 2e-6
+    # the scratch holds, per query, the 32-column blocks some key of its band can read (include/loco_asr.h); the rest is untouched
+    want = (qd @ ped.t())
+    got = scratch.cpu()
+    formed = torch.zeros_like(got, dtype=torch.bool)
+    for b in range(B):
+        nk = 64 * (((int(fr[b]) if fr is not None else T) + 63) // 64)   # keys up to the end of the last key tile
+        for i0 in range(0, T, 32):
+            lo, hi = max(i0 - (nk - 1), -160), min(i0 + 31, 159)
+            formed[b, :, i0:i0 + 32, 32 * ((lo + 160) // 32):32 * ((hi + 160) // 32) + 32] = True
+    assert bool(torch.isnan(got[~formed]).all()) and bool(torch.isfinite(got[formed]).all())
+    assert rel_l2(got[formed], want[formed]) < 2e-6
+    if T == 249:
+        assert 0.5 < float(formed.float().mean()) < 0.9   # an utterance-length clip: a good part of the table is never formed
+    scratch = torch.where(formed.cuda(), scratch, torch.zeros_like(scratch))  # the external-table form below reads columns 0 / 319 of every row
     ref = oracle.attention_core(qd, k.double(), v.double(), ped, None if fr is None else fr.long(), q_block=128).transpose(1, 2).reshape(B, T, 768)
     assert bool(torch.isfinite(ctx).all()) and rel_l2(ctx, ref) < 1e-5
     ctx2 = torch.empty_like(ctx)
