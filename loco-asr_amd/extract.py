@@ -434,6 +434,9 @@ def main(argv=None):
     pack_window = max(1, args.pack_window)
     if pack:
         processor.pin_memory = False  # batches are copied into the pack's pinned buffer: their own staging need not be pinned
+    if pack * args.batch_size > 512:
+        raise SystemExit(f"--pack {pack} x --batch-size {args.batch_size} = {pack * args.batch_size} clips per launch sequence; the library takes "
+                         "at most 512 (loco_max_pack_clips) -- and gains nothing beyond ~128 clips of utterance length")
     if pack and args.bucket_by_length:
         raise SystemExit("--pack keeps the reference's batches (it packs WHOLE batches); --bucket-by-length re-forms them: use one or the other")
     # --pack G: a "round" is one pack of up to G of this rank's batches; equal on all ranks, so that collectives line up
