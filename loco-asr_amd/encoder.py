@@ -192,6 +192,7 @@ class ForwardTicket:
         self._precision = precision
         self._pack = pack  # packed forward: per-clip lengths and per-batch spans
         self._spans = pack.spans if pack is not None else None
+        self._hidden = None  # packed forward with output_hidden_states: layers + 1 tensors [B, T, 768]
         self._done = torch.cuda.Event()
         self._resolved = False
         self._error = None
@@ -221,7 +222,9 @@ class ForwardTicket:
     def _value(self):
         if self._spans is None:
             return BaseModelOutput(last_hidden_state=self._out, hidden_states=None, attentions=None)
-        return [BaseModelOutput(last_hidden_state=self._out[b0:b0 + nb, :t], hidden_states=None, attentions=None)
+        hs = self._hidden
+        return [BaseModelOutput(last_hidden_state=self._out[b0:b0 + nb, :t],
+                                hidden_states=tuple(h[b0:b0 + nb, :t] for h in hs) if hs is not None else None, attentions=None)
                 for (b0, nb, t) in self._spans]
 
     def _settle_locked(self):
@@ -234,7 +237,7 @@ class ForwardTicket:
                 rc = enc._lib.loco_status_check(C.c_void_p(slot.status.data_ptr()), None, 0)
                 if rc == -5 and enc.range_policy == "fp32":
                     with torch.cuda.device(self._out.device), torch.cuda.stream(slot.stream):
-                        extra = () if self._pack is None else (self._pack,)
+                        extra = () if self._pack is None else (self._pack, self._hidden)
                         enc._enqueue(slot, self._x, self._m, self._out, self._frames, "f32", *extra)
                         slot.stream.synchronize()
                     self.used_fp32 = True
@@ -435,7 +438,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         self._ensure_handle(self._device())
         self._workspace_floor = max(self._workspace_floor, int(self._lib.loco_workspace_bytes(self._handle, batch, samples)))
 
-    def _enqueue(self, slot, x, m, out, frames, precision, pack=None):
+    def _enqueue(self, slot, x, m, out, frames, precision, pack=None, hidden=None):
         B, L = x.shape
         need = int(self._lib.loco_workspace_bytes(self._handle, B, L))
         if slot.workspace is None or slot.workspace.numel() < need:
@@ -454,9 +457,10 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
                 C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_async")
         else:
             vl = (C.c_int64 * B)(*pack.valid_len) if pack.valid_len is not None else None
+            hs_ptrs = (C.c_void_p * len(hidden))(*[t.data_ptr() for t in hidden]) if hidden is not None else None
             _lib.check(self._lib.loco_forward_packed(
                 self._handle, self.PRECISIONS[precision], C.c_void_p(x.data_ptr()), mp, vl, B, L, (C.c_int64 * B)(*pack.pad_len),
-                C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), None, C.c_void_p(slot.workspace.data_ptr()),
+                C.c_void_p(out.data_ptr()), C.c_void_p(frames.data_ptr()), hs_ptrs, C.c_void_p(slot.workspace.data_ptr()),
                 slot.workspace.numel(), C.c_void_p(slot.stream.cuda_stream), C.c_void_p(slot.status.data_ptr())), "loco_forward_packed")
 
     @torch.no_grad()
@@ -490,7 +494,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             m = attention_mask.to(device=device, dtype=torch.int32).contiguous()
         return self._submit(x, m, T)
 
-    def _submit(self, x, m, T, pack=None):
+    def _submit(self, x, m, T, pack=None, hidden_states=False):
         """Enqueue one (plain or packed) forward on the next slot.  ``out`` / ``frames`` are allocated on the CALLER's current
         stream (the slot's stream is ordered behind it before the forward, and the caller's stream behind the forward's completion
         event is what ``result()`` provides on the host): a consumer that uses them on its own stream after ``result()`` needs no
@@ -516,14 +520,16 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
             else:
                 out = torch.empty((B, T, HIDDEN), dtype=torch.float32, device=device)
             frames = torch.empty((B,), dtype=torch.int32, device=device)
+            hidden = [torch.empty_like(out) for _ in range(self.num_layers + 1)] if (hidden_states and pack is not None) else None
             slot.stream.wait_stream(cur)
             with torch.cuda.stream(slot.stream):
-                for t in (x, m, out, frames):
+                for t in [x, m, out, frames] + (hidden or []):
                     if t is not None:
                         t.record_stream(slot.stream)
                 ticket = ForwardTicket(self, slot, x, m, out, frames, self.precision, pack)
+                ticket._hidden = hidden
                 t2 = time.perf_counter() if prof is not None else 0.0
-                self._enqueue(slot, x, m, out, frames, self.precision, pack)
+                self._enqueue(slot, x, m, out, frames, self.precision, pack, hidden)
                 t3 = time.perf_counter() if prof is not None else 0.0
                 ticket._done.record(slot.stream)
         slot.ticket = ticket
@@ -583,7 +589,7 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         return Pack(wav=wav, mask=mask, valid_len=valid_len, pad_len=pad_len, spans=spans)
 
     @torch.no_grad()
-    def forward_packed_async(self, batches=None, *, packed: Optional[Pack] = None) -> ForwardTicket:
+    def forward_packed_async(self, batches=None, *, packed: Optional[Pack] = None, output_hidden_states: bool = False) -> ForwardTicket:
         """Enqueue the reference batches in ``batches`` (see pack_batches) -- or an already packed ``Pack`` -- as one launch
         sequence; ``ticket.result()`` is a list with one BaseModelOutput per batch whose ``last_hidden_state`` [B_i, T_i, 768] (a
         view into the pack's output) is what ``forward`` returns for that batch alone up to the fp32 summation order of the GEMMs
@@ -606,11 +612,12 @@ class SpeechT5EncoderWithSpeechPrenetMI355X(nn.Module):
         if B > int(self._lib.loco_max_pack_clips()):
             raise ValueError(f"a pack holds at most {int(self._lib.loco_max_pack_clips())} clips")
         T = int(self._lib.loco_output_frames(pk.wav.shape[1]))
-        return self._submit(pk.wav, pk.mask, T, pk)
+        return self._submit(pk.wav, pk.mask, T, pk, hidden_states=bool(output_hidden_states))
 
-    def forward_packed(self, batches=None, *, packed=None):
-        """``forward_packed_async(...).result()``: list of per-batch outputs."""
-        return self.forward_packed_async(batches, packed=packed).result()
+    def forward_packed(self, batches=None, *, packed=None, output_hidden_states: bool = False):
+        """``forward_packed_async(...).result()``: list of per-batch outputs (``output_hidden_states=True``: each with the 13 hidden
+        states of its batch, HF modeling_speecht5.py:1287-1313; keeps the pack on one stream)."""
+        return self.forward_packed_async(batches, packed=packed, output_hidden_states=output_hidden_states).result()
 
     def workspace_bytes(self, batch: int, samples: int) -> int:
         self._ensure_handle(self._device())

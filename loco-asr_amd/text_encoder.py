@@ -131,7 +131,7 @@ class SpeechT5EncoderWithTextPrenetMI355X(SpeechT5EncoderWithSpeechPrenetMI355X)
         return ids.to(torch.int32).contiguous(), m
 
     # -- several batches of transcripts in flight (the reference's text loop is batch_size = 2 as well, …base…py:67-68,79-93) --------
-    def _enqueue(self, slot, ids32, m, out, frames, precision, pack=None):  # pack: unused (a text pack is an ordinary masked forward)
+    def _enqueue(self, slot, ids32, m, out, frames, precision, pack=None, hidden=None):  # pack / hidden: unused (a text pack is an ordinary masked forward)
         B, T = ids32.shape
         need = int(self._lib.loco_text_workspace_bytes(self._handle, B, T))
         if slot.workspace is None or slot.workspace.numel() < need:

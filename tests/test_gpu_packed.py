@@ -90,12 +90,22 @@ def test_g2_pair_inside_a_pack_reproduces_the_hf_golden(precision):
     x, msk = la.synth.batch(g["lengths"])
     g2 = dict(input_values=torch.from_numpy(x), attention_mask=torch.from_numpy(msk))
     others = _pairs(6, seed_base=500)
-    outs = enc.forward_packed(others[:3] + [g2] + others[3:])
+    outs = enc.forward_packed(others[:3] + [g2] + others[3:], output_hidden_states=True)
     y = outs[3].last_hidden_state
     assert tuple(y.shape) == (2, 249, 768)
     assert enc.last_frames.cpu().tolist()[6:8] == [249, 149]
     assert rel_l2(y[:, rows], g["hidden_states"][12]) < TOL
     assert abs(float(y.double().norm()) / g["hidden_stats"][12, 0] - 1) < 1e-5
+    # every one of the 13 hidden states of the pair, taken from inside the pack, against HuggingFace's
+    hs = outs[3].hidden_states
+    assert len(hs) == 13 and torch.equal(hs[-1], y)
+    for i, h in enumerate(hs):
+        assert tuple(h.shape) == (2, 249, 768)
+        assert rel_l2(h[:, rows], g["hidden_states"][i]) < TOL, i
+        assert abs(float(h.double().norm()) / g["hidden_stats"][i, 0] - 1) < 1e-5, i
+    # and the pack without hidden states (two streams) gives the same last layer up to nothing at all: same kernels, same rows
+    plain = enc.forward_packed(others[:3] + [g2] + others[3:])[3].last_hidden_state
+    assert rel_l2(plain, y) < PACK_TOL
 
 
 def test_pack_without_masks_and_with_one_stream_and_a_single_batch():
