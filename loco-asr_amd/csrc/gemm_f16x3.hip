@@ -1009,30 +1009,37 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
     // inside one process -- same device, same clocks -- by changing the environment and calling loco_debug_reload_gemm_knobs).
     int tile = gemm_knobs().tile;
     if (tile == 0) {
-        if (a.M >= 1024) {
-            // Measured on MI355X (tools/gemm_split_bench.py --tiles=..., and bench.py with LOCO_GEMM_TILE_NARROW in the two-stream
-            // pipeline): 256x256 / 16 waves wins wherever N is a multiple of 256 and at least one full round of 256 workgroups exists (the
-            // halves of the two-stream schedule fill each other's tails) -- also
-            // for the N = 768 GEMMs (out-proj, FFN2, feature projection: -2.3 % of the whole step against 256x128); K <= 128 (the
-            // relative-position table: two k-tiles, then 128 KiB of stores per tile) is epilogue-bound and runs best as two small
-            // workgroups per CU (128x128 / 4 waves / 64 KiB: -6 %); 256x128 / 8 waves otherwise.  Two workgroups per CU did NOT pay for
-            // the projection GEMMs (128x128: -15...-20 %, 192x128 / 6 waves: -25 %): the L2 -> LDS traffic per FLOP doubles.
-            const long t256 = (long)((a.M + 255) / 256) * (a.N / 256) * a.nb1 * a.nb2;
-            if (a.K <= 128) tile = 4;
-            else tile = (a.N % 256 == 0 && t256 >= 256) ? 1 : 2;
-            if (tile == 1 && !a.co_scheduled && !gemm_knobs().no192) {
-                // Whole rounds of 256 workgroups are what a launch costs: 47 968 x 768 is 564 tiles of 256x256 = 2.2 rounds, paid as 3,
-                // but 750 tiles of 192x256 (12 waves, 112 KiB ring) = 2.93 rounds of a tile 3/4 the size: out-proj -15 %, FFN2 -12 %.
-                // Per FLOP the 192-row form is ~10 % behind (more L2 -> LDS bytes, 3 waves per SIMD), so it is chosen only when its
-                // rounds x rows, so weighted, come out lower -- and not under the two half-batch schedule, where the other stream's
-                // workgroups fill the last round anyway (measured: 256x256 +1.3 % there).
-                const long t192 = (long)((a.M + 191) / 192) * (a.N / 256) * a.nb1 * a.nb2;
-                const long c256 = ((t256 + 255) / 256) * 256 * 10, c192 = ((t192 + 255) / 256) * 192 * 11;
-                if (c192 < c256) tile = 6;
+        const long rows_total = (long)a.M * a.nb1 * a.nb2;
+        if (rows_total >= 1024 && a.K <= 128) {
+            // K <= 128 (the relative-position table as a GEMM: two k-tiles, then 128 KiB of stores per tile) is epilogue-bound and runs
+            // best as two small workgroups per CU (128x128 / 4 waves / 64 KiB: -6 %)
+            tile = 4;
+        } else if (rows_total >= 1024) {
+            // Tile form by a cost model (round 4; tools/gemm_split_bench.py [--pack] --tiles=0,1,2,6): a launch costs whole ROUNDS of 256
+            // workgroups, so  cost(form) = ceil(tiles / 256) x bm x bn / eff(form)  with the per-FLOP efficiencies measured on this part
+            // -- 256x256 / 16 waves 1.0, 192x256 / 12 waves 0.91 (more L2 -> LDS bytes per FLOP, 3 waves per SIMD), 256x128 / 8 waves
+            // 0.80, 128x128 / 4 waves 0.55 -- and tiles counted per batch entry (a conv layer of 64 clips x 799 frames wastes the last
+            // row tile of EVERY clip).  At 30 s x 32 (M = 47 968) it reproduces the choices measured there in round 2: 256x256 for QKV /
+            // FFN1 / the conv layers, 192x256 for the N = 768 GEMMs (750 tiles = 2.93 rounds of a tile 3/4 the size against 2.2 rounds
+            // paid as 3).  Rounds 2-3 applied it only between those two forms and fell back to 256x128 whenever fewer than 256 tiles of
+            // 256x256 existed, and to 128x128 whenever ONE batch entry had fewer than 1024 rows: at the shapes of a pack of utterances
+            // (M = 16 000: 189 tiles of 256x256 for N = 768; conv layers 4-6 with 199-799 frames per clip) that cost 30-65 % on out-proj,
+            // FFN2, the feature projection and the small conv layers -- 219 -> 306, 277 -> 397, 242 -> 302, 201 -> 331 TFLOP/s.
+            // Under the two half-batch schedule the other stream's workgroups fill a partly filled round, so rounds are not rounded up.
+            struct Form { int id, bm, bn; double eff; bool n256; };
+            static const Form kForms[] = {{1, 256, 256, 1.00, true}, {6, 192, 256, 0.91, true}, {2, 256, 128, 0.80, false}, {5, 128, 128, 0.55, false}};
+            double best = 0.0;
+            for (const Form& f : kForms) {
+                if (f.n256 && a.N % 256 != 0) continue;
+                if (f.id == 6 && gemm_knobs().no192) continue;
+                const double tiles = (double)((a.M + f.bm - 1) / f.bm) * ((a.N + f.bn - 1) / f.bn) * a.nb1 * a.nb2;
+                const double rounds = a.co_scheduled ? tiles / 256.0 : (double)(((long)tiles + 255) / 256);
+                const double cost = rounds * f.bm * f.bn / f.eff;
+                if (tile == 0 || cost < best) { tile = f.id; best = cost; }
             }
             if (tile == 2 && gemm_knobs().narrow) tile = gemm_knobs().narrow;  // A/B knob for the GEMMs that would take the 256x128 form
         } else {
-            tile = 5;  // small M (short clips, the text branch, tests): 128 x 128, 4 waves, 3 stages
+            tile = 5;  // small problems (short clips without a split-K workspace, the text branch, tests): 128 x 128, 4 waves, 3 stages
         }
     }
     // ring depths: 256x256 -> three A slots + two W slots = 160 KiB; 192x256 -> 3 + 2 = 136 KiB; 256x128 and the one-per-CU

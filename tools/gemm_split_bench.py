@@ -30,6 +30,11 @@ M = 47968
 shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
           ("featproj", M, 768, 512, 0, False), ("conv1", 47999, 512, 1536, 1, True), ("conv4", 5999, 512, 1536, 1, True),
           ("qp", 1499, 320, 64, 0, False)]  # Qp[b,h] = q[b,:,h,:] pe_k^T: batched over 32 clips x 12 heads, A row stride 768
+if "--pack" in sys.argv:  # the shapes of a pack of 32 pairs of ~4 s utterances: 64 clips x 250 frames (conv layers: 64 clips x 6 399 / 799 frames)
+    M = 16000
+    shapes = [("qkv", M, 2304, 768, 0, False), ("out_proj", M, 768, 768, 2, False), ("ffn1", M, 3072, 768, 1, True), ("ffn2", M, 768, 3072, 2, False),
+              ("featproj", M, 768, 512, 0, False), ("conv1", 6399, 512, 1536, 1, True), ("conv4", 799, 512, 1536, 1, True)]
+    PACK_NB = 64
 if "--epi-study" in sys.argv:  # what the epilogue and the short K loop cost on the FFN1 / QKV shapes
     shapes = [("ffn1", M, 3072, 768, 1, True), ("ffn1_noepi", M, 3072, 768, 0, True), ("ffn1_f32out", M, 3072, 768, 0, False),
               ("ffn1_k1536", M, 3072, 1536, 0, False), ("ffn1_k3072", M, 3072, 3072, 0, False),
@@ -44,7 +49,7 @@ for name, m, n, k, epi, osplit in shapes:
         bufs[name] = (ahi, alo, whi, wlo, None, None, torch.empty(32 * 12 * m, n, device="cuda"), None, None, 32 * 12)
         continue
     conv = name.startswith("conv")
-    nb = 32 if conv else 1
+    nb = (PACK_NB if "--pack" in sys.argv else 32) if conv else 1
     rows = nb * m * 2 + 8 if conv else m
     kk = 512 if conv else k
     ahi = (torch.randn(rows, kk, device="cuda")).half(); alo = (torch.randn(rows, kk, device="cuda") * 1e-3).half()
