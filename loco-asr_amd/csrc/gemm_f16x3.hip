@@ -639,18 +639,23 @@ __global__ __launch_bounds__(64 * WM * WN, WPS ? WPS : (WM * WN) / 4) void gemm_
 // group then see the same slot pattern on complementary row sets, sixteen different slots.  Per k-tile a lane's chunk moves two
 // places within its region (+32 B, across the row end included: three chunks per row per region).  20 KB less LDS, ten DMA
 // instructions fewer per plane, no re-read padding pieces.
-constexpr int PCR_BM = 512, PCR_ROWS = PCR_BM + kPosK, PCR_S = 24;   // frames per tile, input rows per tile, row pitch within a region (halves)
-constexpr int PCR_REG = PCR_ROWS * PCR_S;                            // halves per region (even / odd chunks)
-constexpr int PCR_APL = 2 * PCR_REG;                                 // halves per A plane
-static_assert((PCR_REG * 2) % 256 == 0 && (PCR_ROWS * 3) % 64 == 0, "region = whole bank rows and whole DMA instructions");
+// NI = row groups of 16 frames per wave: 4 -> 512 frames per tile (the form of round 3), 2 -> 256 frames per tile (round 4: clips of
+// utterance length -- a pack's 170 ... 300 frames -- fill half of a 512-frame tile; the launcher picks the cheaper form per T).
+constexpr int PCR_S = 24;                                            // row pitch within a region (halves)
 constexpr int PCR_WPL = kPosCg * SBK;                                // halves per W plane of one k-tile
 constexpr int PCR_WST = 3;                                           // W ring slots
-static_assert((2 * PCR_APL + PCR_WST * 2 * PCR_WPL) * 2 <= 160 * 1024, "LDS");
+template <int NI> struct PcrGeom {
+    static constexpr int BM = 8 * 16 * NI, ROWS = BM + kPosK;        // frames per tile, input rows per tile
+    static constexpr int REG = ROWS * PCR_S, APL = 2 * REG;          // halves per region (even / odd chunks), per A plane
+    static_assert((REG * 2) % 256 == 0 && (ROWS * 3) % 64 == 0, "region = whole bank rows and whole DMA instructions");
+    static_assert((2 * APL + PCR_WST * 2 * PCR_WPL) * 2 <= 160 * 1024, "LDS");
+};
 #define PCR_DMA16(base_, voff_, ldsb_) \
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
 
-template <int TERMS>
+template <int TERMS, int NI>
 __global__ __launch_bounds__(512, 2) void pos_conv_resident_kernel(GemmSplitArgs p) {
+    constexpr int PCR_BM = PcrGeom<NI>::BM, PCR_ROWS = PcrGeom<NI>::ROWS, PCR_REG = PcrGeom<NI>::REG, PCR_APL = PcrGeom<NI>::APL;
     __shared__ __attribute__((aligned(16))) _Float16 lds[2 * PCR_APL + PCR_WST * 2 * PCR_WPL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -691,14 +696,14 @@ __global__ __launch_bounds__(512, 2) void pos_conv_resident_kernel(GemmSplitArgs
     PCR_DMA_W(0, 0)
     PCR_DMA_W(1, 1)
 
-    // fragment addresses (halves).  A: row-group i of this wave = frames 64 wave + 16 i + r16; chunk g8 = 4 kt + q4 -> tap g8 / 6,
+    // fragment addresses (halves).  A: row-group i of this wave = frames 16 NI wave + 16 i + r16; chunk g8 = 4 kt + q4 -> tap g8 / 6,
     // channel 8 (g8 % 6) = region q4 & 1, row frame + tap, piece (g8 % 6) / 2: within its region a lane's chunk index (g8 - parity) / 2
     // grows by two per k-tile and the region is row-major with three chunks per row, so aoff simply advances 16 halves per k-tile.
-    int aoff = (q4 & 1) * PCR_REG + (64 * wave + r16) * PCR_S + 8 * (q4 >> 1);
+    int aoff = (q4 & 1) * PCR_REG + (16 * NI * wave + r16) * PCR_S + 8 * (q4 >> 1);
     const int woff = r16 * SBK + 8 * (q4 ^ (3 * ((r16 >> 2) & 1)));
-    f32x4 acc[4][3];
+    f32x4 acc[NI][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -722,7 +727,7 @@ __global__ __launch_bounds__(512, 2) void pos_conv_resident_kernel(GemmSplitArgs
             if (TERMS == 3) wl[j] = *reinterpret_cast<const h8*>(wb + PCR_WPL + 16 * j * SBK + woff);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const h8 ah = *reinterpret_cast<const h8*>(lds + aoff + 16 * i * PCR_S);
             const h8 al = *reinterpret_cast<const h8*>(lds + PCR_APL + aoff + 16 * i * PCR_S);
 #pragma unroll
@@ -742,8 +747,8 @@ __global__ __launch_bounds__(512, 2) void pos_conv_resident_kernel(GemmSplitArgs
     const long coff = b * p.sC1 + g * p.sC2;
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = t0 + 64 * wave + 16 * i + r16;
+    for (int i = 0; i < NI; ++i) {
+        const int m = t0 + 16 * NI * wave + 16 * i + r16;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_posconv_kernel(GemmSplitArg
 struct GemmKnobs {
     int tile = 0, narrow = 0;
     bool nopersist = false, nocolgroup = false, no192 = false, nosplitk = false, posconv_generic = false;
+    int posconv_ni = 0;
 };
 static GemmKnobs read_gemm_knobs() {
     GemmKnobs k;
@@ -847,6 +853,7 @@ static GemmKnobs read_gemm_knobs() {
     k.nocolgroup = getenv("LOCO_GEMM_NOCOLGROUP") != nullptr;
     k.no192 = getenv("LOCO_GEMM_NO192") != nullptr;
     k.posconv_generic = getenv("LOCO_POSCONV_GENERIC") != nullptr;  // A/B: the positional conv on the generic GEMM kernel (A re-fetched per k-tile)
+    if ((v = getenv("LOCO_POSCONV_NI"))) k.posconv_ni = (atoi(v) == 2 || atoi(v) == 4) ? atoi(v) : 0;  // A/B: force the resident kernel's tile (256 / 512 frames)
     k.nosplitk = getenv("LOCO_GEMM_NOSPLITK") != nullptr;  // A/B: small problems as ONE launch each (no partial sums, no reduction kernel)
     return k;
 }
@@ -946,9 +953,21 @@ hipError_t launch_gemm_split(const GemmSplitArgs& a, hipStream_t s) {
         const bool resident = !gemm_knobs().posconv_generic && a.z1_inner == 1 && a.lda == kPosCg && a.K == kPosK * kPosCg && a.nb2 == kPosGroups &&
                               a.nb1 <= 65535 && a.sA2 == (long)(a.M + kPosK) * kPosCg && ((2 * a.ldw) & 15) == 0;
         if (resident) {
-            const dim3 grid((unsigned)((a.M + PCR_BM - 1) / PCR_BM), kPosGroups, (unsigned)a.nb1);
-            if (a.terms == 2) hipLaunchKernelGGL(pos_conv_resident_kernel<2>, grid, dim3(512), 0, s, a);
-            else hipLaunchKernelGGL(pos_conv_resident_kernel<3>, grid, dim3(512), 0, s, a);
+            // 512- or 256-frame tiles: a tile of the small form costs kSmallTile of a large one (measured, tools/posconv_ab.py: the
+            // weights' k-tile stream and the barriers do not shrink with the rows), so it wins where it saves more than that in
+            // idle rows -- T <= 256, 513 ... 768, ...; never at T = 1 499 (3 x 1.0 against 6 x kSmallTile)
+            constexpr double kSmallTile = 0.62;
+            const int t512 = (a.M + 511) / 512, t256 = (a.M + 255) / 256;
+            int ni = (t256 * kSmallTile < t512) ? 2 : 4;
+            if (gemm_knobs().posconv_ni) ni = gemm_knobs().posconv_ni;  // A/B knob: LOCO_POSCONV_NI=2|4
+            const dim3 grid((unsigned)(ni == 2 ? t256 : t512), kPosGroups, (unsigned)a.nb1);
+            if (ni == 2) {
+                if (a.terms == 2) hipLaunchKernelGGL((pos_conv_resident_kernel<2, 2>), grid, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((pos_conv_resident_kernel<3, 2>), grid, dim3(512), 0, s, a);
+            } else {
+                if (a.terms == 2) hipLaunchKernelGGL((pos_conv_resident_kernel<2, 4>), grid, dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((pos_conv_resident_kernel<3, 4>), grid, dim3(512), 0, s, a);
+            }
             return hipGetLastError();
         }
         if (a.terms == 2)
