@@ -241,7 +241,10 @@ int loco_op_resample(const float* x, int32_t B, int64_t n_in, int64_t x_stride, 
  *   loco_flac_decode  mono  float32 [n] = mean over channels of sample / 2^(bits-1) (what soundfile.read(dtype="float32").mean(axis=1)
  *                     gives the reference), and / or pcm int32 [n, channels] interleaved; either may be NULL; capacity in samples per
  *                     channel; *n_samples = samples decoded.  LOCO_E_INVALID (message: loco_flac_last_error) for a malformed stream, a
- *                     CRC or MD5 mismatch; LOCO_E_WORKSPACE when capacity is too small. */
+ *                     CRC or MD5 mismatch; LOCO_E_WORKSPACE when capacity is too small.
+ * The bytes are untrusted input: every length is checked against nbytes, a frame is parsed before its CRC-16 can be verified and a
+ * crafted file carries valid CRCs anyway, so sample arithmetic wraps instead of overflowing, residuals wider than 32 bits and wasted-bit
+ * counts >= the sample size are refused (tests/test_flac_sanitized.py: ~4 500 damaged streams through an ASan + UBSan build). */
 const char* loco_flac_last_error(void);
 int loco_flac_info(const void* data, size_t nbytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample, int64_t* total_samples);
 int loco_flac_decode(const void* data, size_t nbytes, float* mono, int32_t* pcm, int64_t capacity, int64_t* n_samples, int32_t verify_md5);

@@ -217,6 +217,14 @@ int parse_header(const uint8_t* d, size_t n, StreamInfo& si) {
     return LOCO_OK;
 }
 
+// Sample arithmetic wraps (two's complement in uint64_t) instead of overflowing: a well-formed stream never comes near 2^63 (<= 33-bit
+// samples, 32-bit residuals, 15-bit coefficients), but a frame is PARSED before its CRC-16 can be checked, and a crafted file carries
+// valid CRCs anyway -- predictor feedback over 65 536 samples of garbage must stay defined behaviour (tests/test_flac_sanitized.py
+// runs mutated streams through an ASan + UBSan build of this file).
+inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+inline int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+
 bool read_residual(BitReader& br, int64_t* s, int blocksize, int order) {
     const int method = (int)br.bits(2);
     if (method > 1) return false;
@@ -237,6 +245,7 @@ bool read_residual(BitReader& br, int64_t* s, int blocksize, int order) {
             for (int j = 0; j < count; ++j) {
                 const uint64_t q = br.unary();
                 const uint64_t u = (q << k) | (k ? br.bits(k) : 0);
+                if (u >> 32) return false;  // a residual must fit 32 bits signed (RFC 9639 section 9.2.7.3)
                 s[i++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
             }
         }
@@ -249,7 +258,11 @@ bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
     if (br.bit()) return false;  // padding bit must be 0
     const int type = (int)br.bits(6);
     int wasted = 0;
-    if (br.bit()) wasted = (int)br.unary() + 1;
+    if (br.bit()) {
+        const uint32_t w = br.unary();
+        if (w >= (uint32_t)bps - 1) return false;  // at least one bit of the sample must remain
+        wasted = (int)w + 1;
+    }
     bps -= wasted;
     if (bps < 1 || br.bad) return false;
     if (type == 0) {  // CONSTANT
@@ -266,12 +279,12 @@ bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
             int64_t pred = 0;
             switch (order) {
                 case 1: pred = s[i - 1]; break;
-                case 2: pred = 2 * s[i - 1] - s[i - 2]; break;
-                case 3: pred = 3 * s[i - 1] - 3 * s[i - 2] + s[i - 3]; break;
-                case 4: pred = 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
+                case 2: pred = wsub(wmul(2, s[i - 1]), s[i - 2]); break;
+                case 3: pred = wadd(wmul(3, wsub(s[i - 1], s[i - 2])), s[i - 3]); break;
+                case 4: pred = wsub(wadd(wmul(4, wadd(s[i - 1], s[i - 3])), wmul(-6, s[i - 2])), s[i - 4]); break;
                 default: break;
             }
-            s[i] += pred;
+            s[i] = wadd(s[i], pred);
         }
     } else if (type >= 32) {  // LPC, order (type & 31) + 1
         const int order = (type & 31) + 1;
@@ -286,8 +299,8 @@ bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         if (!read_residual(br, s, blocksize, order)) return false;
         for (int i = order; i < blocksize; ++i) {
             int64_t acc = 0;
-            for (int j = 0; j < order; ++j) acc += coef[j] * s[i - 1 - j];
-            s[i] += acc >> shift;  // arithmetic shift (floor), as the format prescribes
+            for (int j = 0; j < order; ++j) acc = wadd(acc, wmul(coef[j], s[i - 1 - j]));
+            s[i] = wadd(s[i], acc >> shift);  // arithmetic shift (floor), as the format prescribes
         }
     } else {
         return false;  // reserved subframe type
@@ -360,14 +373,14 @@ int decode_stream(const uint8_t* d, size_t n, const StreamInfo& si, bool verify_
         int64_t* c0 = buf.data();
         int64_t* c1 = buf.data() + blocksize;
         if (ch_code == 8) {
-            for (int i = 0; i < blocksize; ++i) c1[i] = c0[i] - c1[i];
+            for (int i = 0; i < blocksize; ++i) c1[i] = wsub(c0[i], c1[i]);
         } else if (ch_code == 9) {
-            for (int i = 0; i < blocksize; ++i) c0[i] += c1[i];
+            for (int i = 0; i < blocksize; ++i) c0[i] = wadd(c0[i], c1[i]);
         } else if (ch_code == 10) {
             for (int i = 0; i < blocksize; ++i) {
                 const int64_t side = c1[i], mid = (int64_t)(((uint64_t)c0[i] << 1) | (uint64_t)(side & 1));
-                c0[i] = (mid + side) >> 1;
-                c1[i] = (mid - side) >> 1;
+                c0[i] = wadd(mid, side) >> 1;
+                c1[i] = wsub(mid, side) >> 1;
             }
         }
         int take = blocksize;

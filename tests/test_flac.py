@@ -99,6 +99,13 @@ def test_sample_sizes(bps):
     nch = pcm.shape[1]
     frames = frames_for(n, 576, lambda k, c: dict(kind="fixed", order=(k + c) % 3 + 1, porder=k % 3, method=1 if bps > 16 else 0), nch=nch,
                         assignment=(lambda k: [10, 8, 9, 1][k % 4]) if nch == 2 else None)
+    if bps == 32:
+        # a residual must fit 32 bits signed (RFC 9639 section 9.2.7.3; the decoder refuses wider ones): the full range incl. both
+        # extremes travels in a VERBATIM block, the predicted blocks carry half-scale samples under orders 0 / 1
+        pcm[0, 0], pcm[1, 0] = -(1 << 31), (1 << 31) - 1
+        pcm[576:] //= 2
+        for k, f in enumerate(frames):
+            f["specs"] = [dict(kind="verbatim")] if k == 0 else [dict(kind="fixed", order=k % 2, porder=k % 3, method=1)]
     for f in frames:
         f["bps_from_streaminfo"] = bps not in fw.BPS_CODES or f["size"] == 100
         if f["size"] % 8:
@@ -112,6 +119,17 @@ def test_sample_sizes(bps):
     scale = np.float32(1.0 / (1 << (bps - 1)))
     want = pcm[:, 0].astype(np.float32) * scale if nch == 1 else (pcm[:, 0].astype(np.float32) * scale + pcm[:, 1].astype(np.float32) * scale) / np.float32(2)
     assert np.array_equal(mono, want)
+
+
+def test_a_residual_wider_than_32_bits_is_refused():
+    """RFC 9639 section 9.2.7.3: residuals fit 32 bits signed.  A third-order predictor on full-scale 32-bit noise produces wider ones;
+    the stream carries valid CRCs and MD5, and the decoder says no instead of computing with them."""
+    pcm = speech_like(576, 32, seed=5)
+    pcm[::2] = (1 << 31) - 1
+    pcm[1::2] = -(1 << 31)
+    data = fw.write_stream(pcm, 32, 16000, [dict(size=576, specs=[dict(kind="fixed", order=3, porder=0, method=1)])])
+    rc, msg, _, _ = decode(data)
+    assert rc != 0 and "malformed subframe" in msg, (rc, msg)
 
 
 def test_unknown_length_variable_block_sizes_and_long_coded_numbers():
@@ -191,7 +209,9 @@ def test_random_streams():
                 elif kind == "lpc":
                     sp["order"] = min(rng.choice([1, 2, 3, 6, 12, 32]), size)
                     sp["precision"] = rng.randint(3, 15)
-                    sp["shift"] = rng.randint(0, sp["precision"])
+                    # random (unfitted) coefficients predict up to 2^(precision - 1 - shift) times the signal: the shift keeps the residual
+                    # inside 32 bits signed, as the format demands of an encoder (the decoder refuses wider residuals)
+                    sp["shift"] = rng.randint(max(0, bps + sp["precision"] - 31), sp["precision"])
                     lim = (1 << (sp["precision"] - 1)) // max(1, sp["order"])
                     sp["coefs"] = [rng.randint(-lim, max(0, lim - 1)) for _ in range(sp["order"])]
                 if kind != "verbatim":
