@@ -268,12 +268,18 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
                 }                                                                                                      \
             }                                                                                                          \
     }
+// The scratch holds 32 rows (queries) of 16 floats (keys); row r starts at 16 r + r / 2 (527 floats in all, rows never overlap).
+// ds_write_b32 / ds_read_b32 are served 32 lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS): a write group is two
+// neighbouring rows x 16 keys -- the rows of a pair start 16 banks apart -- and a read group is one column of all 32 rows, whose starts
+// 16 (r % 2) + r / 2 are the 32 different banks.  (Rows padded to 17 floats, rounds 1-3, were conflict-free for the reads but put key 15
+// of the second row of every write group on the bank of key 0 of the first: SQ_LDS_BANK_CONFLICT = 6.6e6 per launch at 30 s x 32, two
+// extra cycles for each of these stores -- hidden behind the store's own register transfer, so this is a counter put right, not time.)
 #define AX_BAND_ADD(S_, st_)                                                                                           \
     _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                                           \
-        _Pragma("unroll") for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bandv[st_][half][u];                \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) sc[66 * u + band_wr] = bandv[st_][half][u];                      \
         __builtin_amdgcn_wave_barrier();                                                                               \
         _Pragma("unroll") for (int e8 = 0; e8 < 8; ++e8)                                                               \
-            S_[8 * half + e8] += sc[r * 17 + (e8 & 3) + 8 * (e8 >> 2) + 4 * h];                                        \
+            S_[8 * half + e8] += sc[band_rd + (e8 & 3) + 8 * (e8 >> 2)];                                               \
         __builtin_amdgcn_wave_barrier();                                                                               \
     }
 #define AX_FINISH_TILE(S0_, S1_, tt_, mx_)                                                                             \
@@ -290,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16x3_kernel(const _Float16*
         } else {                                                                                                       \
             float* sc = bias_stage[wave];                                                                              \
             const int lj = lane & 15, lq = lane >> 4;                                                                  \
+            const int band_wr = 16 * lq + (lq >> 1) + lj, band_rd = 16 * r + (r >> 1) + 4 * h;                         \
             AX_BAND_ADD(S0_, 0)                                                                                        \
             AX_BAND_ADD(S1_, 1)                                                                                        \
             redo = true;                                                                                               \

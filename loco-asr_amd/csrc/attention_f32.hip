@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
                         bv[u] = qpb[(long)(i < T ? i : T - 1) * kRelN + rel + kRelMax];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sc[(4 * u + lq) * 17 + lj] = bv[u];
+                    for (int u = 0; u < 8; ++u) sc[66 * u + 16 * lq + (lq >> 1) + lj] = bv[u];  // row r at 16 r + r / 2: attention_f16x3.hip, AX_BAND_ADD
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int e8 = 0; e8 < 8; ++e8) {
                         const int e = 8 * half + e8;  // keys 16*half + (e8&3) + 8*(e8>>2) + 4h
-                        s[st][e] = fmaf(sc[r * 17 + (e8 & 3) + 8 * (e8 >> 2) + 4 * h], kLog2e, s[st][e]);
+                        s[st][e] = fmaf(sc[16 * r + (r >> 1) + 4 * h + (e8 & 3) + 8 * (e8 >> 2)], kLog2e, s[st][e]);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

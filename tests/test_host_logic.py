@@ -366,3 +366,26 @@ def test_pack_clips_is_the_processor_batch_by_batch(normalize):
         fe.pack_clips([[np.zeros(399, np.float32)]], "cpu", la.synth.conv_out_length)
     with pytest.raises(ValueError, match="empty batch"):
         fe.pack_clips([[]], "cpu", la.synth.conv_out_length)
+
+
+def test_attention_band_scratch_layout_is_a_bijection_without_bank_conflicts():
+    """attention_f16x3.hip / attention_f32.hip, AX_BAND_ADD: the per-wave transpose scratch of the relative-position band stores
+    element (query row, key column) at 16 row + row // 2 + column.  The layout must be a bijection inside the 32 x 17 floats the
+    kernels allot, and -- ds_write_b32 / ds_read_b32 being served 32 lanes at a time over 32 banks -- every write group (two
+    neighbouring rows x 16 columns; the kernel's address is 66 u + 16 lq + lq // 2 + lj for row 4 u + lq) and every read group
+    (one column of the 32 rows) must touch 32 different banks."""
+    addr = lambda row, col: 16 * row + (row >> 1) + col
+    cells = {addr(r, c) for r in range(32) for c in range(16)}
+    assert len(cells) == 512 and max(cells) < 32 * 17
+    for u in range(8):
+        for lq in range(4):
+            for lj in range(16):
+                assert 66 * u + 16 * lq + (lq >> 1) + lj == addr(4 * u + lq, lj)
+        for pair in (0, 2):
+            assert len({addr(4 * u + pair + i, lj) % 32 for i in range(2) for lj in range(16)}) == 32
+    for col in range(16):
+        assert len({addr(r, col) % 32 for r in range(32)}) == 32
+    # the layout of rounds 1-3 (rows padded to 17 floats), for the record: reads conflict-free, every write group one bank short
+    old = lambda row, col: 17 * row + col
+    assert len({old(r, 0) % 32 for r in range(32)}) == 32
+    assert len({old(i, lj) % 32 for i in range(2) for lj in range(16)}) == 31
