@@ -36,6 +36,18 @@ struct BitReader {
     bool bad = false;
     BitReader(const uint8_t* d, size_t bytes) : p(d), n(bytes) {}
     void refill() {
+        if (cnt > 56) return;
+        if (byte + 8 <= n) {
+            // one unaligned big-endian load tops the window up to 56 .. 63 bits: whole bytes only are taken from p, the fraction of the
+            // following byte that the OR brings in below them is masked off again (unary() relies on zeros below `cnt`)
+            uint64_t w;
+            memcpy(&w, p + byte, 8);
+            acc |= __builtin_bswap64(w) >> cnt;
+            byte += (size_t)((63 - cnt) >> 3);
+            cnt |= 56;
+            acc &= ~(~0ull >> cnt);
+            return;
+        }
         while (cnt <= 56 && byte < n) {
             acc |= (uint64_t)p[byte++] << (56 - cnt);
             cnt += 8;
@@ -48,8 +60,10 @@ struct BitReader {
             const uint64_t hi = bits(k - 32);
             return (hi << 32) | bits(32);
         }
-        refill();
-        if (cnt < k) { bad = true; return 0; }
+        if (cnt < k) {
+            refill();
+            if (cnt < k) { bad = true; return 0; }
+        }
         const uint64_t v = acc >> (64 - k);
         acc <<= k;
         cnt -= k;
@@ -83,7 +97,7 @@ struct BitReader {
 
 struct CrcTables {
     uint8_t t8[256];
-    uint16_t t16[256];
+    uint16_t t16[8][256];  // t16[j][v] = CRC of byte v followed by j zero bytes: eight bytes per step (every byte of a stream passes the CRC-16)
     CrcTables() {
         for (int v = 0; v < 256; ++v) {
             uint8_t c = (uint8_t)v;
@@ -91,8 +105,10 @@ struct CrcTables {
             t8[v] = c;
             uint16_t w = (uint16_t)(v << 8);
             for (int b = 0; b < 8; ++b) w = (uint16_t)((w & 0x8000) ? (w << 1) ^ 0x8005 : (w << 1));  // x^16 + x^15 + x^2 + 1
-            t16[v] = w;
+            t16[0][v] = w;
         }
+        for (int j = 1; j < 8; ++j)
+            for (int v = 0; v < 256; ++v) t16[j][v] = (uint16_t)((t16[j - 1][v] << 8) ^ t16[0][t16[j - 1][v] >> 8]);
     }
 };
 const CrcTables& crc_tables() {
@@ -108,7 +124,13 @@ uint8_t crc8(const uint8_t* d, size_t n) {  // init 0, MSB first
 uint16_t crc16(const uint8_t* d, size_t n) {  // init 0, MSB first
     const CrcTables& t = crc_tables();
     uint16_t c = 0;
-    for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ t.t16[(c >> 8) ^ d[i]]);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {  // the running CRC enters the first two bytes, then eight independent table reads
+        const uint8_t b0 = (uint8_t)(d[i] ^ (c >> 8)), b1 = (uint8_t)(d[i + 1] ^ (c & 0xff));
+        c = (uint16_t)(t.t16[7][b0] ^ t.t16[6][b1] ^ t.t16[5][d[i + 2]] ^ t.t16[4][d[i + 3]] ^ t.t16[3][d[i + 4]] ^ t.t16[2][d[i + 5]] ^
+                       t.t16[1][d[i + 6]] ^ t.t16[0][d[i + 7]]);
+    }
+    for (; i < n; ++i) c = (uint16_t)((c << 8) ^ t.t16[0][(c >> 8) ^ d[i]]);
     return c;
 }
 
@@ -225,7 +247,7 @@ inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint
 inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
 inline int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
 
-bool read_residual(BitReader& br, int64_t* s, int blocksize, int order) {
+__attribute__((always_inline)) inline bool read_residual_body(BitReader& br, int64_t* s, int blocksize, int order) {
     const int method = (int)br.bits(2);
     if (method > 1) return false;
     const int pbits = method == 0 ? 4 : 5, esc = method == 0 ? 15 : 31;
@@ -243,8 +265,18 @@ bool read_residual(BitReader& br, int64_t* s, int blocksize, int order) {
             for (int j = 0; j < count; ++j) s[i++] = nb ? br.sbits(nb) : 0;
         } else {
             for (int j = 0; j < count; ++j) {
-                const uint64_t q = br.unary();
-                const uint64_t u = (q << k) | (k ? br.bits(k) : 0);
+                br.refill();
+                uint64_t u;
+                const int z = br.acc ? __builtin_clzll(br.acc) : 64;
+                if (z + 1 + k <= br.cnt) {  // the whole code -- z zeros, the one, k low bits -- lies in the window: one count, two shifts
+                    const uint64_t rest = br.acc << z << 1;
+                    u = ((uint64_t)z << k) | (k ? rest >> (64 - k) : 0);
+                    br.acc = k ? rest << k : rest;
+                    br.cnt -= z + 1 + k;
+                } else {  // a long run of zeros, or the end of the stream
+                    const uint64_t q = br.unary();
+                    u = (q << k) | (k ? br.bits(k) : 0);
+                }
                 if (u >> 32) return false;  // a residual must fit 32 bits signed (RFC 9639 section 9.2.7.3)
                 s[i++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
             }
@@ -252,6 +284,39 @@ bool read_residual(BitReader& br, int64_t* s, int blocksize, int order) {
         if (br.bad) return false;
     }
     return i == blocksize;
+}
+bool read_residual(BitReader& outer, int64_t* s, int blocksize, int order) {
+    BitReader br = outer;  // a local whose address never escapes: the window, its fill and the byte position live in registers over the
+    const bool ok = read_residual_body(br, s, blocksize, order);  // Rice loop (through the reference every store to s[] forces a reload)
+    outer = br;
+    return ok;
+}
+
+// s[i] += (sum_j coef[j] * s[i - 1 - j]) >> shift for i = order .. n - 1, the order a compile-time constant for the common ones
+template <int ORDER>
+void lpc_restore_fixed_order(int64_t* s, int n, const int64_t* coef, int shift) {
+    int64_t c[ORDER];
+    for (int j = 0; j < ORDER; ++j) c[j] = coef[j];
+    for (int i = ORDER; i < n; ++i) {
+        int64_t acc = 0;
+#pragma GCC unroll 32
+        for (int j = 0; j < ORDER; ++j) acc = wadd(acc, wmul(c[j], s[i - 1 - j]));
+        s[i] = wadd(s[i], acc >> shift);  // arithmetic shift (floor), as the format prescribes
+    }
+}
+void lpc_restore(int64_t* s, int n, const int64_t* coef, int order, int shift) {
+    switch (order) {
+#define LOCO_LPC_CASE(o_) case o_: lpc_restore_fixed_order<o_>(s, n, coef, shift); return;
+        LOCO_LPC_CASE(1) LOCO_LPC_CASE(2) LOCO_LPC_CASE(3) LOCO_LPC_CASE(4) LOCO_LPC_CASE(5) LOCO_LPC_CASE(6) LOCO_LPC_CASE(7) LOCO_LPC_CASE(8)
+        LOCO_LPC_CASE(9) LOCO_LPC_CASE(10) LOCO_LPC_CASE(11) LOCO_LPC_CASE(12)
+#undef LOCO_LPC_CASE
+        default: break;
+    }
+    for (int i = order; i < n; ++i) {
+        int64_t acc = 0;
+        for (int j = 0; j < order; ++j) acc = wadd(acc, wmul(coef[j], s[i - 1 - j]));
+        s[i] = wadd(s[i], acc >> shift);
+    }
 }
 
 bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
@@ -297,11 +362,7 @@ bool read_subframe(BitReader& br, int64_t* s, int blocksize, int bps) {
         int64_t coef[32];
         for (int i = 0; i < order; ++i) coef[i] = br.sbits(prec);
         if (!read_residual(br, s, blocksize, order)) return false;
-        for (int i = order; i < blocksize; ++i) {
-            int64_t acc = 0;
-            for (int j = 0; j < order; ++j) acc = wadd(acc, wmul(coef[j], s[i - 1 - j]));
-            s[i] = wadd(s[i], acc >> shift);  // arithmetic shift (floor), as the format prescribes
-        }
+        lpc_restore(s, blocksize, coef, order, shift);
     } else {
         return false;  // reserved subframe type
     }
@@ -388,11 +449,20 @@ int decode_stream(const uint8_t* d, size_t n, const StreamInfo& si, bool verify_
         if (verify_md5) {
             pcm.resize((size_t)take * channels * bytes_ps);
             size_t w = 0;
-            for (int i = 0; i < take; ++i)
-                for (int c = 0; c < channels; ++c) {
-                    const int64_t v = buf[(size_t)c * blocksize + i];
-                    for (int b = 0; b < bytes_ps; ++b) pcm[w++] = (uint8_t)((uint64_t)v >> (8 * b));
+            if (bytes_ps == 2 && channels == 1) {  // the corpus case (16-bit mono): little-endian int16, two bytes per sample
+                for (int i = 0; i < take; ++i) {
+                    const uint64_t v = (uint64_t)buf[i];
+                    pcm[w] = (uint8_t)v;
+                    pcm[w + 1] = (uint8_t)(v >> 8);
+                    w += 2;
                 }
+            } else {
+                for (int i = 0; i < take; ++i)
+                    for (int c = 0; c < channels; ++c) {
+                        const int64_t v = buf[(size_t)c * blocksize + i];
+                        for (int b = 0; b < bytes_ps; ++b) pcm[w++] = (uint8_t)((uint64_t)v >> (8 * b));
+                    }
+            }
             md5.update(pcm.data(), pcm.size());
         }
         sink(buf.data(), blocksize, take, channels);
@@ -442,6 +512,11 @@ int loco_flac_decode(const void* data, size_t nbytes, float* mono, int32_t* pcm,
     bool overflow = false;
     auto sink = [&](const int64_t* s, int blocksize, int take, int channels) {
         if (at + take > capacity) { overflow = true; return; }
+        if (!pcm && channels == 1) {  // the corpus case: one channel, float output only
+            for (int i = 0; i < take; ++i) mono[at + i] = (float)s[i] * scale;
+            at += take;
+            return;
+        }
         for (int i = 0; i < take; ++i) {
             if (pcm)
                 for (int c = 0; c < channels; ++c) pcm[(at + i) * channels + c] = (int32_t)s[(size_t)c * blocksize + i];

@@ -14,7 +14,6 @@ la = importlib.import_module("loco-asr_amd")
 nums = [a for a in sys.argv[1:] if a.isdigit()]
 N = int(nums[0]) if nums else 2000
 R = int(nums[1]) if len(nums) > 1 else 3
-extra = [a for a in sys.argv[1:] if not a.isdigit()] if len(sys.argv) > 1 else []
 extra = sys.argv[1 + len(nums):]
 shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
 root = tempfile.mkdtemp(prefix="cold_corpus_", dir=shm)
@@ -24,16 +23,43 @@ with open(os.path.join(ROOT, "loco-asr_amd", "data", "slurp_intent_classes.txt")
     classes = sorted(l.strip() for l in fh if l.strip())
 
 
+FLAC = "--flac" in extra  # SLURP's own format: files written by the test suite's plain-Python FLAC writer (16-bit mono, 4 096-sample blocks, an
+if FLAC:                  # eighth-order LPC subframe with Rice partitions) -- slow to write, so 256 distinct files are written and the corpus cycles them
+    extra.remove("--flac")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+DISTINCT = min(N, 256) if FLAC else N
+EXT = "flac" if FLAC else "wav"
+
+
 def write_clip(i):
-    wavfile.write(os.path.join(root, "audio", "slurp_real", f"audio-{i:06d}.wav"), 16000, np.clip(la.synth.clip(i, lens[i]) * 32768.0, -32768, 32767).astype(np.int16))
+    pcm = np.clip(la.synth.clip(i, lens[i]) * 32768.0, -32768, 32767).astype(np.int16)
+    path = os.path.join(root, "audio", "slurp_real", f"audio-{i:06d}.{EXT}")
+    if not FLAC:
+        wavfile.write(path, 16000, pcm)
+        return
+    import flac_writer as fw
+    frames, at = [], 0
+    while at < len(pcm):
+        size = min(4096, len(pcm) - at)
+        spec = dict(kind="lpc", order=8, precision=12, shift=10, coefs=[900, -300, 120, -60, 30, -10, 5, -2], porder=3 if size == 4096 else 0, method=0)
+        frames.append(dict(size=size, specs=[spec]))
+        at += size
+    with open(path, "wb") as fh:
+        fh.write(fw.write_stream(pcm.astype(np.int64)[:, None], 16, 16000, frames))
 
 
-with ThreadPoolExecutor(16) as ex:
-    list(ex.map(write_clip, range(N)))
+if FLAC:
+    import multiprocessing as mp
+    with mp.Pool(16) as pool_:
+        pool_.map(write_clip, range(DISTINCT))
+    lens = [lens[i % DISTINCT] for i in range(N)]
+else:
+    with ThreadPoolExecutor(16) as ex:
+        list(ex.map(write_clip, range(N)))
 with open(os.path.join(root, "dataset", "slurp", "devel.jsonl"), "w") as fh:
     for i in range(N):
-        fh.write(json.dumps({"slurp_id": i, "sentence": "", "intent": classes[i % 101], "recordings": [{"file": f"audio-{i:06d}.wav"}]}) + "\n")
-print(f"corpus: {N} WAV files of 2-6 s under {root}; extract.py arguments: --pack 32 {' '.join(extra)}", flush=True)
+        fh.write(json.dumps({"slurp_id": i, "sentence": "", "intent": classes[i % 101], "recordings": [{"file": f"audio-{i % DISTINCT:06d}.{EXT}"}]}) + "\n")
+print(f"corpus: {N} {EXT.upper()} files of 2-6 s ({DISTINCT} distinct) under {root}; extract.py arguments: --pack 32 {' '.join(extra)}", flush=True)
 env = dict(os.environ, LOCO_EXTRACT_PROFILE="1")
 for run in range(R):
     out = tempfile.mkdtemp(prefix="cold_out_", dir=shm)
