@@ -42,6 +42,8 @@ def write_clip(i):
     while at < len(pcm):
         size = min(4096, len(pcm) - at)
         spec = dict(kind="lpc", order=8, precision=12, shift=10, coefs=[900, -300, 120, -60, 30, -10, 5, -2], porder=3 if size == 4096 else 0, method=0)
+        if size < 16:  # a last block shorter than the predictor
+            spec = dict(kind="verbatim")
         frames.append(dict(size=size, specs=[spec]))
         at += size
     with open(path, "wb") as fh:
