@@ -70,17 +70,25 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
 
     // staging map: float4 index f = tid + 256*q  ->  row f/8, k4 = f%8
     const int srow = tid >> 3, sk = (tid & 7) * 4;
-    const float* ga[4];
-    const float* gw[4];
+    // Staging loads are BUFFER loads: one resource descriptor per operand (the tile's first row as base: four scalar registers), a
+    // 32-bit byte offset per staged row that never changes, and the k advance in the instruction's scalar offset.  As eight 64-bit
+    // pointers bumped every k-tile they were sixteen VGPRs (+ their additions) of a kernel that sits at the 256-register limit of its
+    // two-workgroups-per-CU form: the blocked accumulation below had eight staging registers spilling inside the loop.
+    const __amdgpu_buffer_rsrc_t Abase = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long)m0 * p.lda), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Wbase = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (long)n0 * p.ldw), 0, 0x7ffffff0, 0x00020000);
+    unsigned oa[4], ow[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int ra = m0 + srow + 32 * q;
-        ra = ra < p.M ? ra : p.M - 1;  // clamp: rows past M are computed on valid data and never stored
-        int rw = n0 + srow + 32 * q;
-        rw = rw < p.N ? rw : p.N - 1;
-        ga[q] = A + (long)ra * p.lda + sk;
-        gw[q] = W + (long)rw * p.ldw + sk;
+        int ra = srow + 32 * q;
+        ra = m0 + ra < p.M ? ra : p.M - 1 - m0;  // clamp: rows past M are computed on valid data and never stored
+        int rw = srow + 32 * q;
+        rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
+        oa[q] = 4u * (unsigned)(ra * p.lda + sk);
+        ow[q] = 4u * (unsigned)(rw * p.ldw + sk);
     }
+    typedef int loco_i32x4 __attribute__((ext_vector_type(4)));
+#define LOCO_GA(q_, koff_) __builtin_bit_cast(f32x4, (loco_i32x4)__builtin_amdgcn_raw_buffer_load_b128(Abase, oa[q_], 4 * (int)(koff_), 0))
+#define LOCO_GW(q_, koff_) __builtin_bit_cast(f32x4, (loco_i32x4)__builtin_amdgcn_raw_buffer_load_b128(Wbase, ow[q_], 4 * (int)(koff_), 0))
 
     // BLOCKED ACCUMULATION (round 3).  One v_mfma_f32_32x32x2_f32 adds two products to its accumulator, so a dot product over K is a
     // chain of K/2 roundings -- 384 for K = 768, 1 536 for the second feed-forward GEMM -- where a CPU GEMM's vector lanes and
@@ -88,10 +96,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     // family (golden g10) this mode was 2-4x torch's fp32 error per layer and 2e-4 of HF-in-float64 by layer 7 -- the "exact"
     // fallback less accurate than the default split mode it backs up.  Every four k-tiles the running block sum `acc` is folded into
     // `tot` (64 vector adds per lane) and restarted: chains of 64 roundings per block and K / 128 block sums.  g10: 2.0e-4 -> 1.0e-4
-    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the 256
-    // registers of the two-workgroups-per-CU form (eight of the staging registers spill inside the loop) -- this mode's GEMM goes from
-    // 0.80 to 0.74 of the fp32 MFMA peak (104 -> 113 ms per 30 s x 32 step).  It is the accuracy fallback: accuracy wins.  (Folding
-    // every eight k-tiles instead costs the same registers and gave 1.14e-4 / 6.2e-5.)
+    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the
+    // registers of the two-workgroups-per-CU form; with 64-bit staging pointers eight staging registers spilled inside the loop and
+    // this mode's GEMM went from 0.80 to 0.69-0.74 of the fp32 MFMA peak -- the buffer-load staging above (round 4: 241 VGPRs, no
+    // scratch) brought it back to 0.80 with the blocked sums in place.  (Folding every eight k-tiles instead costs the same registers
+    // and gave 1.14e-4 / 6.2e-5.)
     f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -111,8 +120,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     f32x4 ra4[4], rw4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        ra4[q] = *reinterpret_cast<const f32x4*>(ga[q]);
-        rw4[q] = *reinterpret_cast<const f32x4*>(gw[q]);
+        ra4[q] = LOCO_GA(q, 0);
+        rw4[q] = LOCO_GW(q, 0);
     }
     {
         float* la = lds[0];
@@ -154,8 +163,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     if (nk > 1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ra4[q] = *reinterpret_cast<const f32x4*>(ga[q] + BK);
-            rw4[q] = *reinterpret_cast<const f32x4*>(gw[q] + BK);
+            ra4[q] = LOCO_GA(q, BK);
+            rw4[q] = LOCO_GW(q, BK);
         }
     }
 
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
         const bool more = kt + 1 < nk;                                                          \
         if (kt + 2 < nk) {                                                                      \
             _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
-                NA[q] = *reinterpret_cast<const f32x4*>(ga[q] + (long)(kt + 2) * BK);           \
-                NW[q] = *reinterpret_cast<const f32x4*>(gw[q] + (long)(kt + 2) * BK);           \
+                NA[q] = LOCO_GA(q, (kt + 2) * BK);                                            \
+                NW[q] = LOCO_GW(q, (kt + 2) * BK);                                            \
             }                                                                                   \
         }                                                                                       \
         const float* lb = lds[cur];                                                             \
@@ -212,6 +221,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
 #undef LOCO_LOAD_FRAGS
 #undef LOCO_MFMA16
 #undef LOCO_FLUSH_ACC
+#undef LOCO_GA
+#undef LOCO_GW
 
     // epilogue.  The MFMAs were issued as D = W_tile * A_tile^T, so acc[i][j][e] is
     //   C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]:

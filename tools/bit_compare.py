@@ -17,6 +17,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
                                                          {k: torch.from_numpy(v) for k, v in enc_sd.items()}).cuda()
     enc = m.speecht5.encoder
+    enc.precision = os.environ.get("LOCO_BITCMP_PRECISION", enc.precision)  # --precision f32: the exact-fp32 kernel set
     for name, lens in (("pair 5 s + 3.7 s", [80000, 59200]), ("4 x 30 s", [480000] * 4)):
         x, msk = la.synth.batch(lens, first_index=7)
         st = {}
@@ -27,7 +28,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
               + " ".join(sh(h) for h in out.hidden_states), flush=True)
     sys.exit(0)
 
-for lib in sys.argv[1:]:
+for lib in [a for a in sys.argv[1:] if a.endswith('.so')]:
     env = dict(os.environ, LOCO_ASR_LIB=os.path.abspath(lib), LOCO_ALLOW_BANNED_ISA="1")
+    if "--precision" in sys.argv:
+        env["LOCO_BITCMP_PRECISION"] = sys.argv[sys.argv.index("--precision") + 1]
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
     print(f"== {lib}\n{r.stdout}{r.stderr[-400:] if r.returncode else ''}", flush=True)
