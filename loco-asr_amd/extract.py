@@ -136,26 +136,29 @@ def load_audio_16k(path: str, device=None):
             _soundfile = soundfile
         except ImportError:
             _soundfile = False
-    got = read_pcm_wav(path) if path.lower().endswith(".wav") else None
-    if got is None and path.lower().endswith(".flac") and not _soundfile:
-        got = read_flac(path)  # SLURP's own format, decoded by the library (include/loco_asr.h, loco_flac_decode): no libsndfile needed
-    if got is not None:
-        sr, x = got
-    elif _soundfile:
-        x, sr = _soundfile.read(path, dtype="float32", always_2d=True)
-        x = x.mean(axis=1)
-    else:
-        from scipy.io import wavfile
-        if not path.lower().endswith(".wav"):
-            raise RuntimeError(f"cannot decode {path}: install soundfile for FLAC, or convert to WAV")
-        sr, x = wavfile.read(path)
-        if x.dtype.kind == "i":
-            x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
-        elif x.dtype.kind == "u":  # 8-bit PCM is unsigned
-            x = (x.astype(np.float32) - 128.0) / 128.0
-        x = x.astype(np.float32)
-        if x.ndim == 2:
+    try:
+        got = read_pcm_wav(path) if path.lower().endswith(".wav") else None
+        if got is None and path.lower().endswith(".flac") and not _soundfile:
+            got = read_flac(path)  # SLURP's own format, decoded by the library (include/loco_asr.h, loco_flac_decode): no libsndfile needed
+        if got is not None:
+            sr, x = got
+        elif _soundfile:
+            x, sr = _soundfile.read(path, dtype="float32", always_2d=True)
             x = x.mean(axis=1)
+        else:
+            from scipy.io import wavfile
+            if not path.lower().endswith(".wav"):
+                raise RuntimeError("install soundfile for this format, or convert to WAV / FLAC")
+            sr, x = wavfile.read(path)
+            if x.dtype.kind == "i":
+                x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+            elif x.dtype.kind == "u":  # 8-bit PCM is unsigned
+                x = (x.astype(np.float32) - 128.0) / 128.0
+            x = x.astype(np.float32)
+            if x.ndim == 2:
+                x = x.mean(axis=1)
+    except Exception as e:  # a corpus of 100 000 files: the message must say WHICH one
+        raise RuntimeError(str(e) if path in str(e) else f"cannot decode {path}: {e}") from e
     if sr != 16000:
         return importlib.import_module("loco-asr_amd.resample").resample_to_16k(x, int(sr), device=device)
     return x
@@ -665,6 +668,8 @@ def main(argv=None):
                     print("inside forward_async / forward_packed_async, s:", {k_: round(v_, 4) for k_, v_ in encoder.submit_profile.items()})
                 print("main thread, ms per %s: wait for the staged batch %.3f, H2D %.3f, enqueue %.3f, hand-over / finish %.3f"
                       % (("pack" if pack else "batch",) + tuple(1e3 * v_ / max(1, n_packs if pack else n_rounds) for v_ in prof)))
+        except BaseException as e:  # noqa: BLE001 -- a failure of THIS thread (an unreadable file, a refused forward): handled below like the consumer's
+            failure.insert(0, e)
         finally:
             if consumer:
                 todo.put(None)

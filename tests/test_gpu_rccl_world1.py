@@ -154,3 +154,33 @@ def test_bench_gpus_two_on_a_one_gpu_box_fails_for_lack_of_a_device_not_of_a_lau
     assert "needs 2 GPUs on this node, 1 visible" in out, out[-3000:]
     assert "torch.distributed.run" not in out.split("needs 2 GPUs")[0][-400:] or True  # the launcher's own chatter may mention itself
     assert "--gpus 2 but WORLD_SIZE" not in out and "launch N > 1 with" not in out
+
+
+@pytest.mark.parametrize("extra", [[], ["--pack", "2"]], ids=["inflight", "pack"])
+def test_a_rank_that_cannot_read_a_file_takes_the_job_down_instead_of_leaving_the_others_in_a_collective(tmp_path, extra):
+    """ADVICE r3 (low, extract.py): under --gather every rank must reach every round's collectives.  A rank whose LOADER fails -- here
+    an undecodable recording in the middle of the corpus -- used to unwind through the producing thread while the other ranks waited
+    in all_gather; now it prints the error and exits non-zero at once (the launcher tears the job down), whichever thread failed."""
+    import json
+    import numpy as np
+    from scipy.io import wavfile
+    root = tmp_path / "slurp"
+    (root / "dataset" / "slurp").mkdir(parents=True)
+    (root / "audio" / "slurp_real").mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    with open(root / "dataset" / "slurp" / "devel.jsonl", "w") as fh:
+        for i in range(8):
+            path = root / "audio" / "slurp_real" / f"audio-{i}.wav"
+            if i == 5:
+                path.write_bytes(b"RIFF" + bytes(rng.integers(0, 256, 200, dtype=np.uint8)))  # not a WAVE file
+            else:
+                wavfile.write(path, 16000, (rng.standard_normal(16000 + 800 * i) * 3000).astype(np.int16))
+            fh.write(json.dumps({"slurp_id": i, "sentence": "", "intent": "alarm_set", "recordings": [{"file": f"audio-{i}.wav"}]}) + "\n")
+    env = dict(_launcher_env(), LOCO_FORCE_COLLECTIVE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "loco-asr_amd", "extract.py"), "-m", "audio", "-s", "devel",
+           "--data-path", str(root), "--random-init", "--gather", "--out", str(tmp_path / "out")] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)  # a hang would be the timeout
+    assert r.returncode != 0
+    assert "audio-5.wav" in r.stderr or "audio-5.wav" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "Done!" not in r.stdout
