@@ -223,6 +223,7 @@ def extract_text(args, items, classes, encode_labels, device, world, rank):
         tokenize = lambda idx: [np.asarray(tok(items[i][1])["input_ids"], dtype=np.int64) for i in idx]
     from collections import deque
     enc = model.speecht5.encoder
+    enc.precision, enc.range_policy = getattr(args, "precision", enc.precision), getattr(args, "range_policy", enc.range_policy)
     inflight = args.inflight if args.inflight > 0 else 4
     if inflight > 1:
         enc.set_inflight(inflight)  # batches of transcripts are tiny (<= 2 x ~100 tokens): several in flight, results untouched
@@ -331,6 +332,13 @@ def main(argv=None):
                     help="sys.setswitchinterval for the run, in ms (CPython's default is 5): the thread that enqueues forwards gives the "
                          "interpreter lock up at every library call and, with a dozen loader / writer threads runnable, waits a switch "
                          "interval per thread to get it back; 0 = leave the interpreter's setting alone")
+    ap.add_argument("--precision", choices=["f16x3", "f32", "f16x2"], default="f16x3",
+                    help="arithmetic of the contractions (include/loco_asr.h, loco_set_precision): f16x3 (default) = three fp16 MFMAs per "
+                         "fp32-class product, ~1e-6 of an fp64 evaluation; f32 = every contraction on the exact fp32 MFMA (2.7x slower); "
+                         "f16x2 = weights rounded to fp16, ~9e-4: at the 1e-3 bar, not inside it")
+    ap.add_argument("--range-policy", choices=["fp32", "raise", "off"], default="fp32",
+                    help="a batch whose activations leave the range of the fp16 planes (f16x3 / f16x2) is run again on the exact-fp32 "
+                         "kernels (fp32, default), refused with an error (raise), or not checked at all (off)")
     ap.add_argument("--window-seconds", type=float, default=0.0,
                     help="cut every recording into windows of this many seconds (10-minute windows for hour-long podcasts, "
                          "BASELINE.json configs[3]); each window is an independent unit written as <id>_w<k>")
@@ -556,6 +564,7 @@ def main(argv=None):
     clip_pool = ThreadPoolExecutor(n_loaders, initializer=on_device) if n_loaders > 1 and args.batch_size >= 8 and args.window_seconds <= 0 else None
     pack_pool = ThreadPoolExecutor(min(4, n_loaders), initializer=on_device) if pack and n_loaders > 0 else None
     encoder = model.speecht5.encoder
+    encoder.precision, encoder.range_policy = args.precision, args.range_policy
     if inflight > 1 or pack:
         encoder.set_inflight(max(1, inflight))
     if pack and inflight > 1:

@@ -201,3 +201,35 @@ def test_extract_cli_pretrained_directory_and_resume(tmp_path):
         assert open(os.path.join(fa, n), "rb").read() == blobs[n], n
     for n, t in mt.items():
         assert os.path.getmtime(os.path.join(fa, n)) == t, n      # untouched
+
+
+def test_extract_cli_precision_and_range_policy_flags(tmp_path):
+    """--precision f32 runs the exact-fp32 kernel set (bit-identical to the module with precision="f32"), the default is f16x3, and
+    the two agree to 5e-6; --range-policy is handed to the encoder."""
+    la = importlib.import_module("loco-asr_amd")
+    extract = importlib.import_module("loco-asr_amd.extract")
+    import torch
+    common = ["-m", "audio", "-s", "devel", "--synthetic", "4", "--synthetic-seconds", "1.5", "--random-init", "--inflight", "1"]
+    outs = {}
+    for name, extra in (("default", []), ("f32", ["--precision", "f32", "--range-policy", "raise"])):
+        out = str(tmp_path / name)
+        extract.main(common + ["--out", out] + extra)
+        outs[name] = out
+    sd = la.synth.encoder_state_dict(0)
+    pre, enc_sd = la.synth.split_state_dict(sd)
+    m = la.SpeechT5ForSpeechToTextMI355X.from_state_dicts({k: torch.from_numpy(v) for k, v in pre.items()},
+                                                         {k: torch.from_numpy(v) for k, v in enc_sd.items()}).cuda()
+    m.speecht5.encoder.precision = "f32"
+    lens = la.synth.mixed_lengths(4, int(1.5 * 16000))
+    fe = la.SpeechT5FeatureExtractorMI355X()
+    for idx in ([0, 1], [2, 3]):
+        b = fe(audio=[la.synth.clip(i, lens[i]) for i in idx], sampling_rate=16000, return_tensors="pt")
+        ref = m.speecht5.encoder(input_values=b["input_values"].cuda(), attention_mask=b["attention_mask"].cuda()).last_hidden_state.cpu().numpy()
+        for row, i in enumerate(idx):
+            emb = {}
+            for name in outs:
+                with open(os.path.join(outs[name], "devel", "audio", f"synthetic-{i:06d}_embedding_and_target.pickle"), "rb") as fh:
+                    emb[name] = pickle.load(fh)["embedding"]
+            assert np.array_equal(emb["f32"], ref[row])
+            assert not np.array_equal(emb["default"], emb["f32"])
+            assert np.linalg.norm(emb["default"].astype(np.float64) - emb["f32"]) / np.linalg.norm(emb["f32"].astype(np.float64)) < 5e-6
