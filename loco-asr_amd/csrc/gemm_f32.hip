@@ -13,16 +13,17 @@
 // probe), gfx950 has no xf32, so fp32-in MFMA is the matrix-core path for this workload.
 //
 // Tiling: 128x128 block tile, BK = 32, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA
-// tiles (64 accumulator VGPRs), 2 workgroups per CU.  A/W tiles are staged global -> registers -> LDS
-// (16-byte accesses) through two LDS buffers with one barrier per k-tile.  Three levels of software
-// pipelining, each measured on the encoder's shapes (MI355X, QKV GEMM 47968x2304x768):
-//   global loads TWO k-tiles ahead (two register sets)         116 -> 128 TFLOP/s together with
-//   LDS fragments a quarter tile ahead, last quarter after the barrier
+// tiles (64 accumulator VGPRs + 64 for the blocked sums), 2 workgroups per CU.  A/W tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, round 4; global -> registers -> LDS with the loads two k-tiles ahead until then) into two unpadded,
+// XOR-swizzled buffers with one barrier per k-tile; the DMA of tile kt + 1 flies under the MFMAs of tile kt.  Measured on the
+// encoder's shapes (MI355X, QKV GEMM 47968x2304x768):
+//   LDS fragments a quarter tile ahead, last quarter after the barrier          116 -> 128 TFLOP/s (with the register staging's
+//                                                                               two-ahead global loads)
 //   D = W_tile * A_tile^T so a lane owns 4 consecutive n       95 -> 120 TFLOP/s on the N=768 GEMMs
 //   -> 16-byte epilogue stores (the dword store tail was issue-bound)
 // The 32x32x2 instruction consumes k = {lane>>5}; lane-half h owns the contiguous k range [16h, 16h+16) of
-// the tile so that fragments are read with ds_read_b128.  LDS rows are padded to 36 floats: a 16-lane
-// ds_read_b128 group then covers all 64 banks exactly once.
+// the tile so that fragments are read with ds_read_b128 (four 16-byte pieces per row and lane half, at the positions the swizzle
+// gave them: conflict-free, see the kernel).
 //
 // Block -> tile map is XCD-aware: blocks b and b+8 share an XCD (and its private 4 MiB L2), so each XCD
 // is given a contiguous run of tiles with n fastest -- every n-tile of one A row-panel is computed on
@@ -32,7 +33,6 @@
 namespace loco {
 
 constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDT = BK + 4;  // padded LDS row (floats)
 constexpr int kGemmThreads = 256;
 
 struct TileCoord {
@@ -52,9 +52,13 @@ __device__ __forceinline__ TileCoord map_block(int bid, int nblk, int tiles_m, i
     return c;
 }
 
+typedef __attribute__((address_space(3))) void* f32_lptr_t;
+
 template <int EPI>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, int tiles_m, int tiles_n, int nblk) {
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDT];
+    // two buffers of (BM + BN) rows x 32 floats, UNPADDED: tiles arrive by LDS-DMA (one wave instruction = 1 KiB = eight whole rows), the
+    // 16-byte pieces of a row XOR-swizzled on the SOURCE address so that the fragment reads below stay conflict-free (see swz)
+    __shared__ __attribute__((aligned(1024))) float lds[2][(BM + BN) * BK];
 
     const TileCoord tc = map_block(blockIdx.x, nblk, tiles_m, tiles_n);
     const int z1 = tc.z / p.nb2, z2 = tc.z % p.nb2;
@@ -64,31 +68,47 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     const int m0 = tc.mt * BM, n0 = tc.nt * BN;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction: kept in an SGPR (the DMA asm takes "s" operands)
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
 
-    // staging map: float4 index f = tid + 256*q  ->  row f/8, k4 = f%8
-    const int srow = tid >> 3, sk = (tid & 7) * 4;
-    // Staging loads are BUFFER loads: one resource descriptor per operand (the tile's first row as base: four scalar registers), a
-    // 32-bit byte offset per staged row that never changes, and the k advance in the instruction's scalar offset.  As eight 64-bit
-    // pointers bumped every k-tile they were sixteen VGPRs (+ their additions) of a kernel that sits at the 256-register limit of its
-    // two-workgroups-per-CU form: the blocked accumulation below had eight staging registers spilling inside the loop.
-    const __amdgpu_buffer_rsrc_t Abase = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A + (long)m0 * p.lda), 0, 0x7ffffff0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t Wbase = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W + (long)n0 * p.ldw), 0, 0x7ffffff0, 0x00020000);
+    // ---- staging: global -> LDS directly (global_load_lds_dwordx4; round 4).  Until then the tiles went global -> registers -> LDS
+    // with the loads two k-tiles ahead: 64 staging VGPRs, eight ds_write_b128 per lane and k-tile (13 cycles each on the store path)
+    // and, once the blocked accumulation had filled the register file, spills.  A DMA instruction of wave w moves rows 32 w + 8 j ..
+    // + 7 of a tile (j = 0 .. 3, A and W alike): lane -> row lane / 8, stored piece lane % 8, which holds source piece
+    // (lane % 8) ^ swz(row), swz(row) = {row bit 4, row bit 3, row bit 1}.  A ds_read_b128 is served in four groups of 16 lanes
+    // ({0-3, 12-15, 20-27}, ...): with one 128-byte row per lane a group must cover both row parities x 8 different pieces, which is
+    // what those three row bits separate (the K tile of attention_f16x3.hip has the same shape and the same swizzle).
+    // Per lane: a constant 32-bit byte offset per instruction (row clamped at M / N: rows past the end are computed on valid data
+    // and never stored); the k advance goes into the wave-uniform base.
+    const int drow = lane >> 3, dpos = lane & 7;
     unsigned oa[4], ow[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int ra = srow + 32 * q;
-        ra = m0 + ra < p.M ? ra : p.M - 1 - m0;  // clamp: rows past M are computed on valid data and never stored
-        int rw = srow + 32 * q;
-        rw = n0 + rw < p.N ? rw : p.N - 1 - n0;
-        oa[q] = 4u * (unsigned)(ra * p.lda + sk);
-        ow[q] = 4u * (unsigned)(rw * p.ldw + sk);
+    for (int j = 0; j < 4; ++j) {
+        const int row = 32 * wave + 8 * j + drow;
+        const int swz = (((row >> 3) & 3) << 1) | ((row >> 1) & 1);
+        const int ra = m0 + row < p.M ? row : p.M - 1 - m0;
+        const int rw = n0 + row < p.N ? row : p.N - 1 - n0;
+        oa[j] = 4u * (unsigned)(ra * p.lda) + 16u * (unsigned)(dpos ^ swz);
+        ow[j] = 4u * (unsigned)(rw * p.ldw) + 16u * (unsigned)(dpos ^ swz);
     }
-    typedef int loco_i32x4 __attribute__((ext_vector_type(4)));
-#define LOCO_GA(q_, koff_) __builtin_bit_cast(f32x4, (loco_i32x4)__builtin_amdgcn_raw_buffer_load_b128(Abase, oa[q_], 4 * (int)(koff_), 0))
-#define LOCO_GW(q_, koff_) __builtin_bit_cast(f32x4, (loco_i32x4)__builtin_amdgcn_raw_buffer_load_b128(Wbase, ow[q_], 4 * (int)(koff_), 0))
+    const char* const Abase = reinterpret_cast<const char*>(A + (long)m0 * p.lda);
+    const char* const Wbase = reinterpret_cast<const char*>(W + (long)n0 * p.ldw);
+    const unsigned lds0 = (unsigned)(unsigned long)(f32_lptr_t)&lds[0][0];
+    constexpr unsigned kBufBytes = (BM + BN) * BK * 4, kWOff = BM * BK * 4;
+#define LOCO_DMA16(base_, voff_, ldsb_) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsb_), "v"(voff_), "s"(base_) : "memory")
+#define LOCO_DMA_TILE(kt_, buf_)                                                                             \
+    {                                                                                                        \
+        const char* ab_ = Abase + (long)(kt_) * (BK * 4);                                                    \
+        const char* wb_ = Wbase + (long)(kt_) * (BK * 4);                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+            const unsigned d_ = lds0 + (unsigned)(buf_) * kBufBytes + (unsigned)(32 * wave + 8 * j) * (BK * 4); \
+            LOCO_DMA16(ab_, oa[j], d_);                                                                      \
+            LOCO_DMA16(wb_, ow[j], d_ + kWOff);                                                              \
+        }                                                                                                    \
+    }
 
     // BLOCKED ACCUMULATION (round 3).  One v_mfma_f32_32x32x2_f32 adds two products to its accumulator, so a dot product over K is a
     // chain of K/2 roundings -- 384 for K = 768, 1 536 for the second feed-forward GEMM -- where a CPU GEMM's vector lanes and
@@ -96,11 +116,9 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
     // family (golden g10) this mode was 2-4x torch's fp32 error per layer and 2e-4 of HF-in-float64 by layer 7 -- the "exact"
     // fallback less accurate than the default split mode it backs up.  Every four k-tiles the running block sum `acc` is folded into
     // `tot` (64 vector adds per lane) and restarted: chains of 64 roundings per block and K / 128 block sums.  g10: 2.0e-4 -> 1.0e-4
-    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  Cost: the second accumulator set fills the
-    // registers of the two-workgroups-per-CU form; with 64-bit staging pointers eight staging registers spilled inside the loop and
-    // this mode's GEMM went from 0.80 to 0.69-0.74 of the fp32 MFMA peak -- the buffer-load staging above (round 4: 241 VGPRs, no
-    // scratch) brought it back to 0.80 with the blocked sums in place.  (Folding every eight k-tiles instead costs the same registers
-    // and gave 1.14e-4 / 6.2e-5.)
+    // at the worst layer, 1.1e-4 -> 4.3e-5 at the last (HF's own fp32 pass: 5.9e-5).  (Folding every eight k-tiles instead gave
+    // 1.14e-4 / 6.2e-5.)  The second accumulator set once filled the register file of the two-workgroups-per-CU form (spills, 0.80 ->
+    // 0.69-0.74 of the fp32 MFMA peak); buffer-load staging (0.80 again) and then the LDS-DMA staging above removed that pressure.
     f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -117,32 +135,26 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
             }                                                                                   \
     }
 
-    f32x4 ra4[4], rw4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        ra4[q] = LOCO_GA(q, 0);
-        rw4[q] = LOCO_GW(q, 0);
-    }
-    {
-        float* la = lds[0];
-        float* lw = lds[0] + BM * LDT;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<f32x4*>(la + (srow + 32 * q) * LDT + sk) = ra4[q];
-            *reinterpret_cast<f32x4*>(lw + (srow + 32 * q) * LDT + sk) = rw4[q];
-        }
-    }
+    const int nk = p.K / BK;
+    LOCO_DMA_TILE(0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // fragment offsets of this lane inside a buffer (floats): A rows wm*64 + {0,32} + r, W rows BM + wn*64 + {0,32} + r
-    const int fa = (wm * 64 + r) * LDT + 16 * h;
-    const int fw = (BM + wn * 64 + r) * LDT + 16 * h;
+    // fragment offsets of this lane inside a buffer (floats): A rows wm*64 + {0,32} + r, W rows BM + wn*64 + {0,32} + r; the lane's
+    // k range [16 h, 16 h + 16) is pieces 4 h .. 4 h + 3 of the row, read where the swizzle put them (swz(row) = swz(r): the row
+    // offsets 64 wm + 32 i do not touch bits 4, 3, 1)
+    const int fswz = (((r >> 3) & 3) << 1) | ((r >> 1) & 1);
+    const int fa = (wm * 64 + r) * BK;
+    const int fw = (BM + wn * 64 + r) * BK;
+    int fq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fq[q] = 4 * ((4 * h + q) ^ fswz);
 
 #define LOCO_LOAD_FRAGS(buf, k4, A0, A1, B0, B1)                                        \
-    A0 = *reinterpret_cast<const f32x4*>((buf) + fa + (k4) * 4);                        \
-    A1 = *reinterpret_cast<const f32x4*>((buf) + fa + 32 * LDT + (k4) * 4);             \
-    B0 = *reinterpret_cast<const f32x4*>((buf) + fw + (k4) * 4);                        \
-    B1 = *reinterpret_cast<const f32x4*>((buf) + fw + 32 * LDT + (k4) * 4);
+    A0 = *reinterpret_cast<const f32x4*>((buf) + fa + fq[k4]);                          \
+    A1 = *reinterpret_cast<const f32x4*>((buf) + fa + 32 * BK + fq[k4]);                \
+    B0 = *reinterpret_cast<const f32x4*>((buf) + fw + fq[k4]);                          \
+    B1 = *reinterpret_cast<const f32x4*>((buf) + fw + 32 * BK + fq[k4]);
 #define LOCO_MFMA16(A0, A1, B0, B1)                                                     \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(B0[e], A0[e], acc[0][0], 0, 0, 0); \
@@ -151,78 +163,43 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_f32_kernel(GemmArgs p, i
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(B1[e], A1[e], acc[1][1], 0, 0, 0); \
     }
 
-    // Software pipeline, skewed by a quarter tile: the fragments of quarter q+1 are read while the 16 MFMAs
-    // of quarter q issue, and the LAST quarter of tile kt is computed AFTER the barrier that publishes tile
-    // kt+1 -- its 1024 MFMA cycles cover the barrier skew and the LDS latency of the next tile's first
-    // fragments, so a wave never waits on LDS with an idle matrix pipe.
-    const int nk = p.K / BK;
+    // Software pipeline: the DMA of tile kt + 1 is issued at the top of k-tile kt into the buffer whose last reads were issued before
+    // the barrier that ended k-tile kt - 1; fragments run a quarter tile ahead of the MFMAs, and the LAST quarter of tile kt is
+    // computed AFTER the barrier that publishes tile kt + 1 -- its 1024 MFMA cycles cover the barrier skew and the LDS latency of the
+    // next tile's first fragments, so a wave never waits on LDS with an idle matrix pipe.
     int cur = 0;
     f32x4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
-    f32x4 rc4[4], rd4[4];  // second staging set: global loads run TWO k-tiles ahead of the MFMAs
     LOCO_LOAD_FRAGS(lds[0], 0, xa0, xa1, xb0, xb1)
-    if (nk > 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ra4[q] = LOCO_GA(q, BK);
-            rw4[q] = LOCO_GW(q, BK);
-        }
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) LOCO_DMA_TILE(kt + 1, cur ^ 1)
+        const float* lb = lds[cur];
+        LOCO_LOAD_FRAGS(lb, 1, ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_MFMA16(xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_LOAD_FRAGS(lb, 2, xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_MFMA16(ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_LOAD_FRAGS(lb, 3, ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_MFMA16(xa0, xa1, xb0, xb1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt + 1 have landed (the compiler does not count asm DMAs)
+        __syncthreads();
+        cur ^= 1;
+        if (more) { LOCO_LOAD_FRAGS(lds[cur], 0, xa0, xa1, xb0, xb1) }
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_MFMA16(ya0, ya1, yb0, yb1)
+        __builtin_amdgcn_sched_barrier(0);
+        LOCO_FLUSH_ACC(4)
     }
-
-#define LOCO_KTILE(SA, SW, NA, NW)                                                              \
-    {                                                                                           \
-        const bool more = kt + 1 < nk;                                                          \
-        if (kt + 2 < nk) {                                                                      \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
-                NA[q] = LOCO_GA(q, (kt + 2) * BK);                                            \
-                NW[q] = LOCO_GW(q, (kt + 2) * BK);                                            \
-            }                                                                                   \
-        }                                                                                       \
-        const float* lb = lds[cur];                                                             \
-        LOCO_LOAD_FRAGS(lb, 1, ya0, ya1, yb0, yb1)                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(xa0, xa1, xb0, xb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_LOAD_FRAGS(lb, 2, xa0, xa1, xb0, xb1)                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_LOAD_FRAGS(lb, 3, ya0, ya1, yb0, yb1)                                              \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(xa0, xa1, xb0, xb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        if (more) {                                                                             \
-            float* na = lds[cur ^ 1];                                                           \
-            float* nw = lds[cur ^ 1] + BM * LDT;                                                \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                     \
-                *reinterpret_cast<f32x4*>(na + (srow + 32 * q) * LDT + sk) = SA[q];             \
-                *reinterpret_cast<f32x4*>(nw + (srow + 32 * q) * LDT + sk) = SW[q];             \
-            }                                                                                   \
-        }                                                                                       \
-        __syncthreads();                                                                        \
-        cur ^= 1;                                                                               \
-        if (more) { LOCO_LOAD_FRAGS(lds[cur], 0, xa0, xa1, xb0, xb1) }                          \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_MFMA16(ya0, ya1, yb0, yb1)                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                      \
-        LOCO_FLUSH_ACC(4)                                                                       \
-    }
-
-    // Software pipeline (see header): global loads two k-tiles ahead (two register sets, loop unrolled by 2),
-    // LDS fragments a quarter tile ahead, last quarter computed after the barrier.
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        LOCO_KTILE(ra4, rw4, rc4, rd4)
-        ++kt;
-        LOCO_KTILE(rc4, rd4, ra4, rw4)
-        --kt;
-    }
-    if (kt < nk) LOCO_KTILE(ra4, rw4, rc4, rd4)
-#undef LOCO_KTILE
 #undef LOCO_LOAD_FRAGS
 #undef LOCO_MFMA16
 #undef LOCO_FLUSH_ACC
-#undef LOCO_GA
-#undef LOCO_GW
+#undef LOCO_DMA_TILE
+#undef LOCO_DMA16
 
     // epilogue.  The MFMAs were issued as D = W_tile * A_tile^T, so acc[i][j][e] is
     //   C[m = m0 + wm*64 + 32i + r][n = n0 + wn*64 + 32j + 8*(e>>2) + 4h + (e&3)]:
