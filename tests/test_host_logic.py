@@ -389,3 +389,18 @@ def test_attention_band_scratch_layout_is_a_bijection_without_bank_conflicts():
     old = lambda row, col: 17 * row + col
     assert len({old(r, 0) % 32 for r in range(32)}) == 32
     assert len({old(i, lj) % 32 for i in range(2) for lj in range(16)}) == 31
+
+
+def test_every_tool_script_still_parses():
+    """tools/ holds the probes DESIGN.md and profiles/ quote; most need a GPU to RUN, but a syntax error or a stale shell construct in
+    one of them should not wait for the next time somebody needs the measurement."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "**", "*.py"), recursive=True)) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(scripts) > 30
+    for path in scripts:
+        with open(path) as fh:
+            compile(fh.read(), path, "exec")  # syntax only: nothing is written, nothing runs
+    for path in sorted(glob.glob(os.path.join(root, "tools", "**", "*.sh"), recursive=True)):
+        subprocess.run(["bash", "-n", path], check=True)
